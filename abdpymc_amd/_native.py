@@ -1,0 +1,310 @@
+"""
+ctypes binding of ``libabd_hip.so`` (C ABI: ``include/abd_hip.h``).
+
+The HIP library is the only implementation of the hot path in this package: if it is missing or fails
+to load, importing the symbols below raises -- there is no CPU fallback (the CPU restatement under
+``oracle/`` is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+N_THETA = 17
+MAX_GAPS = 256
+STORE_F64, STORE_F32 = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("ABD_HIP_LIB", os.path.join(_HERE, "libabd_hip.so"))
+
+
+class AbdError(RuntimeError):
+    """HIP/runtime failure inside the native library."""
+
+
+class _AntigenObs(C.Structure):
+    _fields_ = [
+        ("n_obs", C.c_int64),
+        ("idx_gap", C.POINTER(C.c_int32)),
+        ("idx_ind", C.POINTER(C.c_int32)),
+        ("log_dilution", C.POINTER(C.c_double)),
+        ("od", C.POINTER(C.c_double)),
+    ]
+
+
+class _Desc(C.Structure):
+    _fields_ = [
+        ("n_gaps", C.c_int32),
+        ("n_inds", C.c_int32),
+        ("n_splits", C.c_int32),
+        ("splits", C.c_int32 * 2),
+        ("storage", C.c_int32),
+        ("n_chain_slots", C.c_int32),
+        ("device", C.c_int32),
+        ("s", _AntigenObs),
+        ("n", _AntigenObs),
+        ("vacs", C.POINTER(C.c_int8)),
+        ("pcrpos", C.POINTER(C.c_int8)),
+    ]
+
+
+_lib = None
+
+# every symbol include/abd_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I32 = C.POINTER(C.c_int32)
+_I8 = C.POINTER(C.c_int8)
+SYMBOLS = {
+    "abd_version": (C.c_char_p, []),
+    "abd_last_error": (C.c_char_p, []),
+    "abd_create": (C.c_int, [C.POINTER(_Desc), C.POINTER(_P)]),
+    "abd_destroy": (C.c_int, [_P]),
+    "abd_device_name": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "abd_set_discrete": (C.c_int, [_P, C.c_int32, _I8, _I8]),
+    "abd_flip_discrete": (C.c_int, [_P, C.c_int32, C.c_int64]),
+    "abd_logp": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "abd_logp_dlogp": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "abd_logp_dlogp_batch": (C.c_int, [_P, C.c_int32, _I32, _D, _D, _D]),
+    "abd_n_result_slots": (C.c_int, [_P]),
+    "abd_logp_dlogp_batch_enqueue": (C.c_int, [_P, C.c_int32, C.c_int32, _I32, _D]),
+    "abd_wait": (C.c_int, [_P]),
+    "abd_fetch": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "abd_deterministics": (C.c_int, [_P, C.c_int32, _D, _I8, _D, _D]),
+    "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
+    "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
+    "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
+    "abd_is_dense": (C.c_int, [_P]),
+}
+
+
+def load():
+    """Load the HIP library (once).  Raises ImportError loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"abdpymc_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the hot path."
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _err(lib) -> str:
+    return lib.abd_last_error().decode("utf-8", "replace")
+
+
+def _check(lib, rc: int):
+    if rc == 0:
+        return
+    msg = _err(lib)
+    if rc == -1:  # ABD_ERR_ARG -> the reference raises ValueError for the same conditions
+        raise ValueError(msg)
+    raise AbdError(f"[{rc}] {msg}")
+
+
+def _as(arr, dtype):
+    return np.ascontiguousarray(arr, dtype=dtype)
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+    """
+    Device-resident cohort + chain slots.  Mirrors what ``abd.model(data, splits, ignore_pcrpos)``
+    closes over (reference abd.py:396-442).
+    """
+
+    def __init__(
+        self,
+        n_gaps: int,
+        n_inds: int,
+        s_obs,  # (idx_gap, idx_ind, log_dilution, od)
+        n_obs,
+        vacs,  # (N, G)
+        pcrpos,  # (N, G) or None (= ignore_pcrpos)
+        splits: Optional[Sequence[int]] = None,
+        n_chains: int = 1,
+        storage: str = "f64",
+        device: int = -1,
+    ):
+        lib = load()
+        self._lib = lib
+        self._h = _P()
+        self.n_gaps, self.n_inds, self.n_chains = int(n_gaps), int(n_inds), int(n_chains)
+        d = _Desc()
+        d.n_gaps, d.n_inds = self.n_gaps, self.n_inds
+        splits = tuple(splits or ())
+        if len(splits) > 2:
+            raise NotImplementedError("only implemented 1-3 time chunks (0-2 splits)")
+        d.n_splits = len(splits)
+        for k, s in enumerate(splits):
+            d.splits[k] = int(s)
+        d.storage = {"f64": STORE_F64, "f32": STORE_F32}[storage]
+        d.n_chain_slots = self.n_chains
+        d.device = device
+        keep = []
+
+        def obs(o):
+            g, j, x, y = o
+            g, j = _as(g, np.int32), _as(j, np.int32)
+            x, y = _as(x, np.float64), _as(y, np.float64)
+            if not (g.shape == j.shape == x.shape == y.shape and g.ndim == 1):
+                raise ValueError("observation arrays must be 1-D and of equal length")
+            keep.extend([g, j, x, y])
+            a = _AntigenObs()
+            a.n_obs = g.size
+            a.idx_gap, a.idx_ind = _ptr(g, C.c_int32), _ptr(j, C.c_int32)
+            a.log_dilution, a.od = _ptr(x, C.c_double), _ptr(y, C.c_double)
+            return a
+
+        d.s, d.n = obs(s_obs), obs(n_obs)
+        vacs = np.asarray(vacs)
+        if vacs.shape != (self.n_inds, self.n_gaps):
+            raise ValueError(f"vacs shape {vacs.shape} != (n_inds, n_gaps) = {(self.n_inds, self.n_gaps)}")
+        v8 = _as(vacs, np.int8)
+        if not np.array_equal(v8, vacs):
+            raise ValueError("vacs must be 0/1")
+        keep.append(v8)
+        d.vacs = _ptr(v8, C.c_int8)
+        if pcrpos is not None:
+            pcrpos = np.asarray(pcrpos)
+            if vacs.shape != pcrpos.shape:
+                raise ValueError("vacs and pcrpos are different shapes")  # abd.py:196-197
+            p8 = _as(pcrpos, np.int8)
+            if not np.array_equal(p8, pcrpos):
+                raise ValueError("pcrpos must be 0/1")
+            keep.append(p8)
+            d.pcrpos = _ptr(p8, C.c_int8)
+        _check(lib, lib.abd_create(C.byref(d), C.byref(self._h)))
+        self.n_result_slots = lib.abd_n_result_slots(self._h)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.abd_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- info -------------------------------------------------------------------------------
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(self._lib, self._lib.abd_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def is_dense(self) -> bool:
+        return bool(self._lib.abd_is_dense(self._h))
+
+    def algorithmic_bytes(self, n_chains: int) -> int:
+        return int(self._lib.abd_algorithmic_bytes(self._h, n_chains))
+
+    # -- discrete state -----------------------------------------------------------------------
+    def set_discrete(self, chain: int, i_raw, waner):
+        i_raw, waner = np.asarray(i_raw), np.asarray(waner)
+        if i_raw.shape != (self.n_gaps, self.n_inds):
+            raise ValueError(f"i_raw shape {i_raw.shape} != (n_gaps, n_inds) = {(self.n_gaps, self.n_inds)}")
+        if waner.shape != (self.n_inds,):
+            raise ValueError(f"ab_s_waner shape {waner.shape} != ({self.n_inds},)")
+        i8, w8 = _as(i_raw, np.int8), _as(waner, np.int8)
+        if not (np.array_equal(i8, i_raw) and np.array_equal(w8, waner)):
+            raise ValueError("i_raw / ab_s_waner must be 0/1")
+        _check(self._lib, self._lib.abd_set_discrete(self._h, chain, _ptr(i8, C.c_int8), _ptr(w8, C.c_int8)))
+
+    def flip_discrete(self, chain: int, flat: int):
+        _check(self._lib, self._lib.abd_flip_discrete(self._h, chain, int(flat)))
+
+    # -- evaluations ------------------------------------------------------------------------
+    def logp(self, chain: int, theta) -> float:
+        t = _as(theta, np.float64)
+        if t.shape != (N_THETA,):
+            raise ValueError(f"theta must have shape ({N_THETA},)")
+        out = C.c_double()
+        _check(self._lib, self._lib.abd_logp(self._h, chain, _ptr(t, C.c_double), C.byref(out)))
+        return out.value
+
+    def logp_dlogp(self, chain: int, theta):
+        t = _as(theta, np.float64)
+        if t.shape != (N_THETA,):
+            raise ValueError(f"theta must have shape ({N_THETA},)")
+        out = C.c_double()
+        g = np.empty(N_THETA)
+        _check(self._lib, self._lib.abd_logp_dlogp(self._h, chain, _ptr(t, C.c_double), C.byref(out), _ptr(g, C.c_double)))
+        return out.value, g
+
+    def logp_dlogp_batch(self, chains, theta):
+        ch = _as(chains, np.int32)
+        t = _as(theta, np.float64)
+        if t.shape != (ch.size, N_THETA):
+            raise ValueError(f"theta must have shape ({ch.size}, {N_THETA})")
+        lp = np.empty(ch.size)
+        g = np.empty((ch.size, N_THETA))
+        _check(
+            self._lib,
+            self._lib.abd_logp_dlogp_batch(
+                self._h, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double), _ptr(lp, C.c_double), _ptr(g, C.c_double)
+            ),
+        )
+        return lp, g
+
+    def enqueue(self, slot: int, chains, theta):
+        ch = _as(chains, np.int32)
+        t = _as(theta, np.float64)
+        if t.shape != (ch.size, N_THETA):
+            raise ValueError(f"theta must have shape ({ch.size}, {N_THETA})")
+        _check(
+            self._lib,
+            self._lib.abd_logp_dlogp_batch_enqueue(self._h, slot, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double)),
+        )
+
+    def wait(self):
+        _check(self._lib, self._lib.abd_wait(self._h))
+
+    def fetch(self, slot: int, n: int):
+        lp = np.empty(n)
+        g = np.empty((n, N_THETA))
+        _check(self._lib, self._lib.abd_fetch(self._h, slot, _ptr(lp, C.c_double), _ptr(g, C.c_double)))
+        return lp, g
+
+    def deterministics(self, chain: int, theta):
+        t = _as(theta, np.float64)
+        G, N = self.n_gaps, self.n_inds
+        i = np.empty((G, N), dtype=np.int8)
+        mun = np.empty((G, N))
+        mus = np.empty((G, N))
+        _check(
+            self._lib,
+            self._lib.abd_deterministics(
+                self._h, chain, _ptr(t, C.c_double), _ptr(i, C.c_int8), _ptr(mun, C.c_double), _ptr(mus, C.c_double)
+            ),
+        )
+        return i, mun, mus
+
+    # -- measurement --------------------------------------------------------------------------
+    def kernel_timing(self, enable: bool):
+        _check(self._lib, self._lib.abd_kernel_timing(self._h, int(enable)))
+
+    def kernel_time(self, reset: bool = True):
+        ms = C.c_double()
+        n = C.c_int64()
+        _check(self._lib, self._lib.abd_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value

@@ -1,0 +1,731 @@
+// abd_capi.hip -- host side of the C ABI declared in include/abd_hip.h.
+//
+// Replaces, for the joint-logp path only, what PyMC/PyTensor compile out of abdpymc.model()
+// (reference abdpymc/abd.py:396-469): the closed-form prior terms + transform Jacobians are evaluated
+// here on the host (17 scalars), the O(G*N) data term on the device (abd_kernels.hpp).
+#include "abd_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/abd_hip.h"
+
+static_assert(ABD_MAX_BATCH == ABD_MAX_BATCH_K, "header / kernel batch size mismatch");
+static_assert(ABD_MAX_GAPS == 64 * ABD_MAXT, "header / kernel gap limit mismatch");
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(ABD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+constexpr int kResultSlots = 1024;
+constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
+
+struct AntigenDev {
+  int64_t K = 0;
+  void* y = nullptr;       // R[K], sorted by (ind, gap)
+  void* x = nullptr;       // R[K]
+  uint8_t* g = nullptr;    // sparse: gap per obs
+  int32_t* ptr = nullptr;  // sparse: (N+1)
+};
+
+struct ChainSlot {
+  int8_t* iraw_ng = nullptr;  // (N, G)
+  int8_t* waner = nullptr;    // (N)
+  bool set = false;
+};
+
+struct ResultSlot {
+  int n = 0;
+  bool grad = true;
+  std::vector<int32_t> chains;
+  std::vector<double> theta;  // n x 17
+};
+
+}  // namespace
+
+struct abd_ctx {
+  int device = 0;
+  int G = 0, N = 0, nt = 0, n_chunks = 1;
+  int storage = ABD_STORE_F64;
+  bool dense = false;
+  bool ignore_pcr = false;
+  int n_slots = 0;
+  int n_cu = 256;
+  int blocks_x = 0;
+  uint64_t chunk_mask[3][ABD_MAXT] = {};
+  AntigenDev s, n;
+  int8_t* vacs = nullptr;
+  int8_t* pcr = nullptr;
+  int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
+  std::vector<ChainSlot> slots;
+  double* partials = nullptr;  // [n_slots][blocks_x][ABD_NOUT]
+  double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
+  double* d_out = nullptr;     // device view of h_out
+  std::vector<ResultSlot> results;
+  hipStream_t stream = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double ev_total_ms = 0.0;
+  int64_t ev_count = 0;
+  char name[256] = {0};
+};
+
+namespace {
+
+struct Transformed {
+  double p, perm_n, temp_n, rho_n, init_n, perm_s, rho_s, q, tinf, tvac, init_s;
+  double b_n, d_n, sig_n, b_s, d_s, sig_s;
+};
+
+inline double sigmoid(double t) { return 1.0 / (1.0 + std::exp(-t)); }
+inline double softplus(double t) { return std::max(t, 0.0) + std::log1p(std::exp(-std::fabs(t))); }
+
+Transformed transform(const double* t) {
+  Transformed c;
+  c.p = sigmoid(t[0]);
+  c.perm_n = std::exp(t[1]);
+  c.temp_n = std::exp(t[2]);
+  c.rho_n = sigmoid(t[3]);
+  c.init_n = t[4];
+  c.perm_s = std::exp(t[5]);
+  c.rho_s = sigmoid(t[6]);
+  c.q = sigmoid(t[7]);
+  c.tinf = std::exp(t[8]);
+  c.tvac = std::exp(t[9]);
+  c.init_s = t[10];
+  c.b_n = t[11];
+  c.d_n = t[12];
+  c.sig_n = std::exp(t[13]);
+  c.b_s = t[14];
+  c.d_s = t[15];
+  c.sig_s = std::exp(t[16]);
+  return c;
+}
+
+// Priors + transform log-Jacobians in closed form, and their gradient.
+//   p ~ Beta(1, G-1), i_raw ~ Bernoulli(p)                         abd.py:424-427
+//   ab_n_perm/temp ~ Gamma, ab_n_rho ~ Beta(10,1), ab_n_init ~ N  abd.py:329-340
+//   ab_s_* likewise, ab_s_waner ~ Bernoulli(p_waner)               abd.py:367-388
+//   it_*_b ~ N(-1,.5), it_*_d ~ N(2,.5), it_*_sigma ~ Exp(1)       abd.py:464-467
+double priors(const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/) {
+  double lp = 0.0;
+  if (g) std::fill(g, g + ABD_N_THETA, 0.0);
+  auto gamma_ab = [](double mu, double sd, double& a, double& b) {
+    a = mu * mu / (sd * sd);
+    b = mu / (sd * sd);
+  };
+  {  // theta0
+    const double L0 = -softplus(-t[0]), L1 = -softplus(t[0]), p = sigmoid(t[0]);
+    const double bm1 = (double)(G - 1) - 1.0;
+    // -lnB(1, G-1) = ln(G-1)
+    const double lnB = std::lgamma(1.0) + std::lgamma((double)(G - 1)) - std::lgamma((double)G);
+    lp += (bm1 == 0.0 ? 0.0 : bm1 * L1) - lnB + L0 + L1 + n1 * L0 + (cells - n1) * L1;
+    if (g) g[0] = (1.0 + n1) * (1.0 - p) - p * (bm1 + 1.0 + (cells - n1));
+  }
+  const int gk[5] = {1, 2, 5, 8, 9};
+  const double gmu[5] = {2.0, 1.0, 2.0, 1.0, 1.0};
+  for (int q = 0; q < 5; ++q) {
+    double al, be;
+    gamma_ab(gmu[q], 0.5, al, be);
+    const double x = std::exp(t[gk[q]]);
+    lp += al * std::log(be) - std::lgamma(al) + al * t[gk[q]] - be * x;
+    if (g) g[gk[q]] = al - be * x;
+  }
+  for (int k : {3, 6}) {
+    const double L0 = -softplus(-t[k]), L1 = -softplus(t[k]), r = sigmoid(t[k]);
+    const double lnB = std::lgamma(10.0) + std::lgamma(1.0) - std::lgamma(11.0);
+    lp += 9.0 * L0 - lnB + L0 + L1;
+    if (g) g[k] = 10.0 * (1.0 - r) - r;
+  }
+  {
+    const double L0 = -softplus(-t[7]), L1 = -softplus(t[7]), q = sigmoid(t[7]);
+    lp += L0 + L1 + m1 * L0 + (N - m1) * L1;
+    if (g) g[7] = (1.0 + m1) * (1.0 - q) - q * (1.0 + (N - m1));
+  }
+  const int nk[6] = {4, 10, 11, 12, 14, 15};
+  const double nmu[6] = {-2.0, -2.0, -1.0, 2.0, -1.0, 2.0};
+  const double nsd[6] = {1.0, 1.0, 0.5, 0.5, 0.5, 0.5};
+  for (int q = 0; q < 6; ++q) {
+    const double z = (t[nk[q]] - nmu[q]) / nsd[q];
+    lp += -0.5 * z * z - std::log(nsd[q]) - 0.5 * kLog2Pi;
+    if (g) g[nk[q]] = -z / nsd[q];
+  }
+  for (int k : {13, 16}) {
+    const double x = std::exp(t[k]);
+    lp += -x + t[k];
+    if (g) g[k] = -x + 1.0;
+  }
+  return lp;
+}
+
+// Combine the device sums of one chain with the host-side terms.
+void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad) {
+  const Transformed tr = transform(t);
+  const double n1 = sums[ABD_NACC], m1 = sums[ABD_NACC + 1];
+  const double cells = (double)c->G * (double)c->N;
+  double lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad);
+  const double Kn = (double)c->n.K, Ks = (double)c->s.K;
+  lp += -0.5 * sums[A_N_R2] - Kn * (t[13] + 0.5 * kLog2Pi);
+  lp += -0.5 * sums[A_S_R2] - Ks * (t[16] + 0.5 * kLog2Pi);
+  *logp = lp;
+  if (grad) {
+    grad[1] += -tr.b_n * tr.perm_n * sums[A_N_HC];
+    grad[2] += -tr.b_n * tr.temp_n * sums[A_N_HU];
+    grad[3] += -tr.b_n * tr.temp_n * tr.rho_n * (1.0 - tr.rho_n) * sums[A_N_HD];
+    grad[4] += -tr.b_n * sums[A_N_H];
+    grad[11] += -sums[A_N_HX];
+    grad[12] += sums[A_N_WS];
+    grad[13] += sums[A_N_R2] - Kn;
+    grad[5] += -tr.b_s * tr.perm_s * sums[A_S_HC];
+    grad[6] += -tr.b_s * tr.rho_s * (1.0 - tr.rho_s) * sums[A_S_HD];
+    grad[10] += -tr.b_s * sums[A_S_H];
+    grad[14] += -sums[A_S_HX];
+    grad[15] += sums[A_S_WS];
+    grad[16] += sums[A_S_R2] - Ks;
+  }
+}
+
+ChainPar chain_par(const abd_ctx* c, int chain, const double* t) {
+  const Transformed tr = transform(t);
+  ChainPar p;
+  p.perm_n = tr.perm_n;
+  p.temp_n = tr.temp_n;
+  p.rho_n = tr.rho_n;
+  p.init_n = tr.init_n;
+  p.perm_s = tr.perm_s;
+  p.rho_s = tr.rho_s;
+  p.init_s = tr.init_s;
+  p.b_n = tr.b_n;
+  p.d_n = tr.d_n;
+  p.isig_n = 1.0 / tr.sig_n;
+  p.b_s = tr.b_s;
+  p.d_s = tr.d_s;
+  p.isig_s = 1.0 / tr.sig_s;
+  p.iraw = c->slots[chain].iraw_ng;
+  p.waner = c->slots[chain].waner;
+  return p;
+}
+
+void base_args(const abd_ctx* c, EvalArgs& a) {
+  std::memset(&a, 0, sizeof a);
+  a.y_n = c->n.y;
+  a.x_n = c->n.x;
+  a.y_s = c->s.y;
+  a.x_s = c->s.x;
+  a.g_n = c->n.g;
+  a.g_s = c->s.g;
+  a.ptr_n = c->n.ptr;
+  a.ptr_s = c->s.ptr;
+  a.vacs = c->vacs;
+  a.pcr = c->ignore_pcr ? nullptr : c->pcr;
+  a.partials = c->partials;
+  a.G = c->G;
+  a.N = c->N;
+  a.nt = c->nt;
+  a.n_chunks = c->n_chunks;
+  std::memcpy(a.chunk_mask, c->chunk_mask, sizeof a.chunk_mask);
+}
+
+size_t eval_lds_bytes(int G, int cpw) {
+  return (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * cpw * ABD_NOUT * sizeof(double);
+}
+
+template <typename R, int CPW, bool DENSE>
+void launch_eval_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  if (grad)
+    hipLaunchKernelGGL((abd_eval_kernel<R, CPW, DENSE, true>), grid, dim3(ABD_BLOCK), lds, st, a);
+  else
+    hipLaunchKernelGGL((abd_eval_kernel<R, CPW, DENSE, false>), grid, dim3(ABD_BLOCK), lds, st, a);
+}
+
+template <typename R, int CPW>
+void launch_eval_d(bool dense, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  if (dense)
+    launch_eval_g<R, CPW, true>(grad, grid, lds, st, a);
+  else
+    launch_eval_g<R, CPW, false>(grad, grid, lds, st, a);
+}
+
+template <typename R>
+void launch_eval_c(int cpw, bool dense, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  switch (cpw) {
+    case 4: launch_eval_d<R, 4>(dense, grad, grid, lds, st, a); break;
+    case 2: launch_eval_d<R, 2>(dense, grad, grid, lds, st, a); break;
+    default: launch_eval_d<R, 1>(dense, grad, grid, lds, st, a); break;
+  }
+}
+
+int pick_cpw(int n) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = std::getenv("ABD_CPW");
+    forced = e ? std::atoi(e) : 0;
+  }
+  if (forced == 1 || forced == 2 || forced == 4) {
+    if (n % forced == 0) return forced;
+  }
+  if (n % 4 == 0) return 4;
+  if (n % 2 == 0) return 2;
+  return 1;
+}
+
+// Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH) whose sums go to out rows [row0, row0+n).
+int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows) {
+  EvalArgs a;
+  base_args(c, a);
+  a.n_chains = n;
+  for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
+  const int cpw = pick_cpw(n);
+  dim3 grid(c->blocks_x, n / cpw);
+  const size_t lds = eval_lds_bytes(c->G, cpw);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing) {
+    if (c->ev_used == c->ev_pool.size()) {
+      hipEvent_t a0, a1;
+      HIP_TRY(hipEventCreate(&a0));
+      HIP_TRY(hipEventCreate(&a1));
+      c->ev_pool.emplace_back(a0, a1);
+    }
+    e0 = c->ev_pool[c->ev_used].first;
+    e1 = c->ev_pool[c->ev_used].second;
+    c->ev_used++;
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
+  if (c->storage == ABD_STORE_F32)
+    launch_eval_c<float>(cpw, c->dense, grad, grid, lds, c->stream, a);
+  else
+    launch_eval_c<double>(cpw, c->dense, grad, grid, lds, c->stream, a);
+  if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(256), 0, c->stream, c->partials, c->blocks_x, d_out_rows);
+  HIP_TRY(hipGetLastError());
+  return ABD_OK;
+}
+
+int check_chains(abd_ctx* c, int n, const int32_t* chains) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (n < 1 || n > c->n_slots) return fail(ABD_ERR_ARG, "n=%d outside [1, n_chain_slots=%d]", n, c->n_slots);
+  for (int k = 0; k < n; ++k) {
+    if (chains[k] < 0 || chains[k] >= c->n_slots) return fail(ABD_ERR_ARG, "chain %d outside [0, %d)", chains[k], c->n_slots);
+    if (!c->slots[chains[k]].set) return fail(ABD_ERR_STATE, "chain slot %d has no discrete state (call abd_set_discrete)", chains[k]);
+  }
+  return ABD_OK;
+}
+
+int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad) {
+  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  int rc = check_chains(c, n, chains);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  ResultSlot& r = c->results[slot];
+  r.n = n;
+  r.grad = grad;
+  r.chains.assign(chains, chains + n);
+  r.theta.assign(theta, theta + (size_t)n * ABD_N_THETA);
+  double* rows = c->d_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
+    const int m = std::min(ABD_MAX_BATCH, n - k0);
+    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT);
+    if (rc) return rc;
+  }
+  return ABD_OK;
+}
+
+int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad) {
+  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  const ResultSlot& r = c->results[slot];
+  if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
+  const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  for (int k = 0; k < r.n; ++k)
+    assemble(c, r.theta.data() + (size_t)k * ABD_N_THETA, rows + (size_t)k * ABD_NOUT, logp + k,
+             (grad && r.grad) ? grad + (size_t)k * ABD_N_THETA : nullptr);
+  return ABD_OK;
+}
+
+// sort one antigen's observations by (ind, gap); returns false on an out-of-range index
+struct SortedObs {
+  std::vector<int64_t> order;  // order[k] = original index
+  std::vector<int32_t> ptr;    // (N+1)
+  bool one_per_cell = false;
+};
+
+int sort_obs(const abd_antigen_obs& o, int G, int N, const char* tag, SortedObs& out) {
+  if (o.n_obs < 0) return fail(ABD_ERR_ARG, "%s: negative n_obs", tag);
+  if (o.n_obs > 0 && (!o.idx_gap || !o.idx_ind || !o.log_dilution || !o.od)) return fail(ABD_ERR_ARG, "%s: NULL observation array", tag);
+  if (o.n_obs >= (int64_t)std::numeric_limits<int32_t>::max()) return fail(ABD_ERR_ARG, "%s: too many observations", tag);
+  const int64_t cells = (int64_t)G * N;
+  std::vector<int32_t> count((size_t)cells + 1, 0);
+  for (int64_t k = 0; k < o.n_obs; ++k) {
+    const int64_t g = o.idx_gap[k], j = o.idx_ind[k];
+    if (g < 0 || g >= G || j < 0 || j >= N) return fail(ABD_ERR_ARG, "%s: observation %lld has (gap=%lld, ind=%lld) outside (%d, %d)", tag, (long long)k, (long long)g, (long long)j, G, N);
+    count[(size_t)(j * G + g) + 1]++;
+  }
+  out.one_per_cell = o.n_obs == cells;
+  for (int64_t cidx = 0; cidx < cells; ++cidx) {
+    if (count[(size_t)cidx + 1] != 1) out.one_per_cell = false;
+    count[(size_t)cidx + 1] += count[(size_t)cidx];
+  }
+  out.order.resize((size_t)o.n_obs);
+  std::vector<int32_t> cursor(count.begin(), count.end() - 1);
+  for (int64_t k = 0; k < o.n_obs; ++k) {
+    const int64_t cell = (int64_t)o.idx_ind[k] * G + o.idx_gap[k];
+    out.order[(size_t)cursor[(size_t)cell]++] = k;  // stable
+  }
+  out.ptr.resize((size_t)N + 1);
+  for (int j = 0; j <= N; ++j) out.ptr[(size_t)j] = count[(size_t)j * G];
+  return ABD_OK;
+}
+
+template <typename R>
+int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, AntigenDev& d) {
+  const size_t K = (size_t)o.n_obs;
+  d.K = o.n_obs;
+  std::vector<R> y(std::max<size_t>(K, 1)), x(std::max<size_t>(K, 1));
+  std::vector<uint8_t> g(std::max<size_t>(K, 1));
+  for (size_t k = 0; k < K; ++k) {
+    const int64_t src = so.order[k];
+    y[k] = (R)o.od[src];
+    x[k] = (R)o.log_dilution[src];
+    g[k] = (uint8_t)o.idx_gap[src];
+  }
+  HIP_TRY(hipMalloc(&d.y, y.size() * sizeof(R)));
+  HIP_TRY(hipMalloc(&d.x, x.size() * sizeof(R)));
+  HIP_TRY(hipMemcpy(d.y, y.data(), y.size() * sizeof(R), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.x, x.data(), x.size() * sizeof(R), hipMemcpyHostToDevice));
+  if (!c->dense) {
+    HIP_TRY(hipMalloc(&d.g, g.size()));
+    HIP_TRY(hipMemcpy(d.g, g.data(), g.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&d.ptr, so.ptr.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(d.ptr, so.ptr.data(), so.ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return ABD_OK;
+}
+
+void free_ctx(abd_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto* a : {&c->s, &c->n}) {
+    if (a->y) (void)hipFree(a->y);
+    if (a->x) (void)hipFree(a->x);
+    if (a->g) (void)hipFree(a->g);
+    if (a->ptr) (void)hipFree(a->ptr);
+  }
+  if (c->vacs) (void)hipFree(c->vacs);
+  if (c->pcr) (void)hipFree(c->pcr);
+  if (c->stage_gn) (void)hipFree(c->stage_gn);
+  for (auto& s : c->slots) {
+    if (s.iraw_ng) (void)hipFree(s.iraw_ng);
+    if (s.waner) (void)hipFree(s.waner);
+  }
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  for (auto& e : c->ev_pool) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* abd_version(void) { return "abdpymc_amd hip gfx950 0.1"; }
+
+const char* abd_last_error(void) { return g_err.c_str(); }
+
+int abd_create(const abd_desc* d, abd_ctx** out) {
+  if (!d || !out) return fail(ABD_ERR_ARG, "desc / out is NULL");
+  *out = nullptr;
+  const int G = d->n_gaps, N = d->n_inds;
+  if (G < 2) return fail(ABD_ERR_ARG, "n_gaps must be >= 2 (Beta(1, n_gaps - 1) prior on p), got %d", G);
+  if (G > ABD_MAX_GAPS) return fail(ABD_ERR_ARG, "n_gaps=%d exceeds ABD_MAX_GAPS=%d", G, ABD_MAX_GAPS);
+  if (N < 1) return fail(ABD_ERR_ARG, "n_inds must be >= 1, got %d", N);
+  if ((int64_t)G * N >= (int64_t)1 << 31) return fail(ABD_ERR_ARG, "n_gaps*n_inds too large");
+  if (d->n_chain_slots < 1) return fail(ABD_ERR_ARG, "n_chain_slots must be >= 1");
+  if (d->storage != ABD_STORE_F64 && d->storage != ABD_STORE_F32) return fail(ABD_ERR_ARG, "unknown storage %d", d->storage);
+  if (!d->vacs) return fail(ABD_ERR_ARG, "vacs is NULL");
+  // check_splits (abd.py:604-622) -- same conditions, same messages
+  if (d->n_splits < 0 || d->n_splits > 2) return fail(ABD_ERR_ARG, "only implemented 1-3 time chunks (0-2 splits)");
+  for (int k = 0; k < d->n_splits; ++k)
+    if (d->splits[k] < 0) return fail(ABD_ERR_ARG, "split indexes must be positive");
+  if (d->n_splits == 2 && d->splits[0] > d->splits[1]) return fail(ABD_ERR_ARG, "splits must be in ascending order");
+  if (d->n_splits > 0 && d->splits[d->n_splits - 1] > G) return fail(ABD_ERR_ARG, "largest split must be less than n_gaps - 1, (%d)", d->splits[d->n_splits - 1]);
+  if (d->n_splits == 2 && d->splits[0] == d->splits[1]) return fail(ABD_ERR_ARG, "splits not unique");
+  for (int64_t k = 0; k < (int64_t)G * N; ++k) {
+    if ((d->vacs[k] != 0 && d->vacs[k] != 1)) return fail(ABD_ERR_ARG, "vacs must be 0/1");
+    if (d->pcrpos && d->pcrpos[k] != 0 && d->pcrpos[k] != 1) return fail(ABD_ERR_ARG, "pcrpos must be 0/1");
+  }
+
+  SortedObs so_s, so_n;
+  int rc = sort_obs(d->s, G, N, "s", so_s);
+  if (rc) return rc;
+  rc = sort_obs(d->n, G, N, "n", so_n);
+  if (rc) return rc;
+
+  abd_ctx* c = new (std::nothrow) abd_ctx();
+  if (!c) return fail(ABD_ERR_NOMEM, "out of host memory");
+  c->G = G;
+  c->N = N;
+  c->nt = (G + 63) / 64;
+  c->n_chunks = d->n_splits + 1;
+  c->storage = d->storage;
+  c->dense = so_s.one_per_cell && so_n.one_per_cell;
+  if (const char* e = std::getenv("ABD_FORCE_SPARSE"))
+    if (std::atoi(e)) c->dense = false;
+  c->ignore_pcr = d->pcrpos == nullptr;
+  c->n_slots = d->n_chain_slots;
+  {
+    const int edges[4] = {0, d->n_splits > 0 ? d->splits[0] : G, d->n_splits > 1 ? d->splits[1] : G, G};
+    for (int ch = 0; ch < c->n_chunks; ++ch) {
+      const int lo = edges[ch], hi = (ch == c->n_chunks - 1) ? G : edges[ch + 1];
+      for (int g = lo; g < hi; ++g) c->chunk_mask[ch][g >> 6] |= 1ull << (g & 63);
+    }
+  }
+
+#define CREATE_TRY(expr)                                                                            \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      fail(ABD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                                    \
+      free_ctx(c);                                                                                  \
+      return ABD_ERR_HIP;                                                                           \
+    }                                                                                               \
+  } while (0)
+
+  int dev = d->device;
+  if (dev < 0) CREATE_TRY(hipGetDevice(&dev));
+  c->device = dev;
+  CREATE_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  CREATE_TRY(hipGetDeviceProperties(&prop, dev));
+  c->n_cu = prop.multiProcessorCount;
+  snprintf(c->name, sizeof c->name, "%s %s %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  int bpc = 2;
+  if (const char* e = std::getenv("ABD_BLOCKS_PER_CU")) bpc = std::max(1, std::atoi(e));
+  c->blocks_x = std::max(1, std::min((N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * bpc));
+
+  if (c->storage == ABD_STORE_F32) {
+    rc = upload_antigen<float>(c, d->s, so_s, c->s);
+    if (!rc) rc = upload_antigen<float>(c, d->n, so_n, c->n);
+  } else {
+    rc = upload_antigen<double>(c, d->s, so_s, c->s);
+    if (!rc) rc = upload_antigen<double>(c, d->n, so_n, c->n);
+  }
+  if (rc) {
+    free_ctx(c);
+    return rc;
+  }
+  const size_t cells = (size_t)G * N;
+  CREATE_TRY(hipMalloc(&c->vacs, cells));
+  CREATE_TRY(hipMemcpy(c->vacs, d->vacs, cells, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&c->pcr, cells));
+  if (d->pcrpos)
+    CREATE_TRY(hipMemcpy(c->pcr, d->pcrpos, cells, hipMemcpyHostToDevice));
+  else
+    CREATE_TRY(hipMemset(c->pcr, 0, cells));
+  CREATE_TRY(hipMalloc(&c->stage_gn, cells));
+  c->slots.resize((size_t)c->n_slots);
+  for (auto& s : c->slots) {
+    CREATE_TRY(hipMalloc(&s.iraw_ng, cells));
+    CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
+  }
+  CREATE_TRY(hipMalloc(&c->partials, (size_t)c->n_slots * c->blocks_x * ABD_NOUT * sizeof(double)));
+  const size_t out_bytes = (size_t)kResultSlots * c->n_slots * ABD_NOUT * sizeof(double);
+  CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
+  std::memset(c->h_out, 0, out_bytes);
+  CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
+  c->results.resize(kResultSlots);
+  // the dense kernels with 4 chains per wave need > 64 KB of dynamic LDS only for very large G; ask once
+  const size_t lds_max = eval_lds_bytes(G, 4);
+  if (lds_max > 64 * 1024) {
+    free_ctx(c);
+    return fail(ABD_ERR_ARG, "LDS table for n_gaps=%d does not fit", G);
+  }
+  CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+  *out = c;
+  return ABD_OK;
+}
+
+int abd_destroy(abd_ctx* c) {
+  free_ctx(c);
+  return ABD_OK;
+}
+
+int abd_device_name(abd_ctx* c, char* buf, int32_t buflen) {
+  if (!c || !buf || buflen < 1) return fail(ABD_ERR_ARG, "bad argument");
+  snprintf(buf, (size_t)buflen, "%s", c->name);
+  return ABD_OK;
+}
+
+int abd_is_dense(abd_ctx* c) { return c && c->dense ? 1 : 0; }
+
+int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_t* waner) {
+  if (!c || !i_raw || !waner) return fail(ABD_ERR_ARG, "NULL argument");
+  if (chain < 0 || chain >= c->n_slots) return fail(ABD_ERR_ARG, "chain %d outside [0, %d)", chain, c->n_slots);
+  const size_t cells = (size_t)c->G * c->N;
+  for (size_t k = 0; k < cells; ++k)
+    if (i_raw[k] != 0 && i_raw[k] != 1) return fail(ABD_ERR_ARG, "i_raw must be 0/1");
+  for (int j = 0; j < c->N; ++j)
+    if (waner[j] != 0 && waner[j] != 1) return fail(ABD_ERR_ARG, "ab_s_waner must be 0/1");
+  HIP_TRY(hipSetDevice(c->device));
+  ChainSlot& s = c->slots[(size_t)chain];
+  // synchronous copies: the caller's buffers may be reused immediately
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(c->stage_gn, i_raw, cells, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s.waner, waner, (size_t)c->N, hipMemcpyHostToDevice));
+  dim3 grid((c->N + 63) / 64, (c->G + 63) / 64);
+  hipLaunchKernelGGL(abd_transpose_i8_kernel, grid, dim3(256), 0, c->stream, c->stage_gn, s.iraw_ng, c->G, c->N);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  s.set = true;
+  return ABD_OK;
+}
+
+int abd_flip_discrete(abd_ctx* c, int32_t chain, int64_t flat) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (chain < 0 || chain >= c->n_slots) return fail(ABD_ERR_ARG, "chain %d outside [0, %d)", chain, c->n_slots);
+  const int64_t total = (int64_t)c->G * c->N + c->N;
+  if (flat < 0 || flat >= total) return fail(ABD_ERR_ARG, "flat index %lld outside [0, %lld)", (long long)flat, (long long)total);
+  if (!c->slots[(size_t)chain].set) return fail(ABD_ERR_STATE, "chain slot %d has no discrete state", chain);
+  HIP_TRY(hipSetDevice(c->device));
+  ChainSlot& s = c->slots[(size_t)chain];
+  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, s.iraw_ng, s.waner, c->G, c->N, flat);
+  HIP_TRY(hipGetLastError());
+  return ABD_OK;
+}
+
+int abd_n_result_slots(abd_ctx*) { return kResultSlots; }
+
+int abd_logp_dlogp_batch_enqueue(abd_ctx* c, int32_t slot, int32_t n, const int32_t* chains, const double* theta) {
+  if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
+  return enqueue_slot(c, slot, n, chains, theta, true);
+}
+
+int abd_wait(abd_ctx* c) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ABD_OK;
+}
+
+int abd_fetch(abd_ctx* c, int32_t slot, double* logp, double* grad) {
+  if (!c || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  return fetch_slot(c, slot, logp, grad);
+}
+
+int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
+  if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
+  int rc = enqueue_slot(c, 0, n, chains, theta, true);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return fetch_slot(c, 0, logp, grad);
+}
+
+int abd_logp_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* logp, double* grad) {
+  return abd_logp_dlogp_batch(c, 1, &chain, theta, logp, grad);
+}
+
+int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {
+  if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  int rc = enqueue_slot(c, 0, 1, &chain, theta, false);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return fetch_slot(c, 0, logp, nullptr);
+}
+
+int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i, double* mu_n, double* mu_s) {
+  if (!c || !theta) return fail(ABD_ERR_ARG, "NULL argument");
+  int rc = check_chains(c, 1, &chain);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t cells = (size_t)c->G * c->N;
+  int8_t* d_i = nullptr;
+  double *d_n = nullptr, *d_s = nullptr;
+  if (i) HIP_TRY(hipMalloc(&d_i, cells));
+  if (mu_n) HIP_TRY(hipMalloc(&d_n, cells * sizeof(double)));
+  if (mu_s) HIP_TRY(hipMalloc(&d_s, cells * sizeof(double)));
+  EvalArgs a;
+  base_args(c, a);
+  a.n_chains = 1;
+  a.ch[0] = chain_par(c, chain, theta);
+  const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
+  hipLaunchKernelGGL(abd_deterministics_kernel, dim3(c->blocks_x), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && i) e = hipMemcpy(i, d_i, cells, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && mu_n) e = hipMemcpy(mu_n, d_n, cells * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && mu_s) e = hipMemcpy(mu_s, d_s, cells * sizeof(double), hipMemcpyDeviceToHost);
+  if (d_i) (void)hipFree(d_i);
+  if (d_n) (void)hipFree(d_n);
+  if (d_s) (void)hipFree(d_s);
+  if (e != hipSuccess) return fail(ABD_ERR_HIP, "deterministics: %s", hipGetErrorString(e));
+  return ABD_OK;
+}
+
+int abd_kernel_timing(abd_ctx* c, int32_t enable) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  c->timing = enable != 0;
+  return ABD_OK;
+}
+
+int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t reset) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < c->ev_used; ++k) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
+    c->ev_total_ms += ms;
+    c->ev_count++;
+  }
+  c->ev_used = 0;
+  if (total_ms) *total_ms = c->ev_total_ms;
+  if (launches) *launches = c->ev_count;
+  if (reset) {
+    c->ev_total_ms = 0.0;
+    c->ev_count = 0;
+  }
+  return ABD_OK;
+}
+
+int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
+  if (!c) return 0;
+  const int64_t R = c->storage == ABD_STORE_F32 ? 4 : 8;
+  const int64_t cells = (int64_t)c->G * c->N;
+  if (c->dense) return cells * (4 * R + 2 + n_chains) + (int64_t)n_chains * c->N;
+  // sparse: per observation od + log_dilution + gap index (held as 1 byte), CSR pointers, three indicator panels
+  return (c->s.K + c->n.K) * (2 * R + 1) + 2 * (int64_t)(c->N + 1) * 4 + cells * (2 + n_chains) + (int64_t)n_chains * c->N;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+/*
+ * abd_hip.h -- C ABI of the MI355X-native abdpymc joint log-probability hot path.
+ *
+ * This is the drop-in boundary for ONE path of davipatti/abdpymc: the joint logp (+ gradient) of the
+ * antibody-dynamics model built by abdpymc.model() (reference abdpymc/abd.py:396-442) and evaluated by
+ * PyMC's two compiled callables inside pm.sample() (reference call site abd.py:922):
+ *
+ *   Model.compile_logp()            point -> scalar logp          -> abd_logp
+ *   Model.logp_dlogp_function()     theta[17] -> (logp, grad[17]) -> abd_logp_dlogp / _batch
+ *   pm.Deterministic "i", "ab_n_mu", "ab_s_mu" (abd.py:649/667, 341, 389-391) -> abd_deterministics
+ *
+ * Plain C: pointers and sizes only.  The caller owns every host buffer passed in or out; the library
+ * copies inputs at abd_create / abd_set_discrete and owns all device memory until abd_destroy.
+ * Every function returns 0 on success and a negative abd_status on error; the message is available from
+ * abd_last_error().  Numerical out-of-range (e.g. exp overflow of a sigma) is NOT an error: logp comes
+ * back -inf / nan with status 0, as PyMC signals it (NUTS marks a divergence).
+ *
+ * theta layout (17 doubles, PyMC value variables in creation order; abd.py:424, 329-340, 367-388, 464-467):
+ *   0 p_logodds__          1 ab_n_perm_log__     2 ab_n_temp_log__     3 ab_n_rho_logodds__   4 ab_n_init
+ *   5 ab_s_perm_log__      6 ab_s_rho_logodds__  7 ab_s_p_waner_logodds__
+ *   8 ab_s_tempinf_log__   9 ab_s_tempvac_log__  10 ab_s_init
+ *   11 it_n_b  12 it_n_d  13 it_n_sigma_log__    14 it_s_b  15 it_s_d  16 it_s_sigma_log__
+ */
+#ifndef ABD_HIP_H
+#define ABD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABD_N_THETA 17
+#define ABD_MAX_GAPS 256  /* gap axis is held as 4 x 64-bit wave-uniform masks */
+#define ABD_MAX_BATCH 16  /* chains per kernel launch (larger batches are split) */
+
+typedef enum {
+  ABD_OK = 0,
+  ABD_ERR_ARG = -1,     /* bad argument (maps to ValueError in the Python mirror)            */
+  ABD_ERR_HIP = -2,     /* HIP runtime failure; message carries hipGetErrorString             */
+  ABD_ERR_STATE = -3,   /* e.g. logp on a chain slot whose discrete state was never set       */
+  ABD_ERR_NOMEM = -4
+} abd_status;
+
+typedef enum { ABD_STORE_F64 = 0, ABD_STORE_F32 = 1 } abd_storage;
+
+/* One antigen's observation list = reference AntigenTiterData (abd.py:22-43): OD readings gathered out
+ * of the (gap, ind) titer matrix by mu[idx_gap, idx_ind] (abd.py:343, 393).  Any order; the library
+ * sorts by (ind, gap) and detects the dense-panel case (exactly one reading in every cell). */
+typedef struct {
+  int64_t n_obs;
+  const int32_t* idx_gap;      /* df.elapsed_months   abd.py:35 */
+  const int32_t* idx_ind;      /* df.individual_i     abd.py:36 */
+  const double* log_dilution;  /* abd.py:462 */
+  const double* od;            /* abd.py:468 */
+} abd_antigen_obs;
+
+/* Everything abd.model(data, splits, ignore_pcrpos) closes over (abd.py:396-442). */
+typedef struct {
+  int32_t n_gaps;              /* G  = TiterData.n_gaps (abd.py:101); Beta prior of p uses it (abd.py:424) */
+  int32_t n_inds;              /* N  = TiterData.n_inds (abd.py:102) */
+  int32_t n_splits;            /* 0, 1 or 2 (abd.py:865-882) */
+  int32_t splits[2];           /* ascending gap indexes, check_splits rules (abd.py:604-622) */
+  int32_t storage;             /* abd_storage: precision the OD / log_dilution panels are HELD in on the device */
+  int32_t n_chain_slots;       /* independent (i_raw, waner) states resident at once */
+  int32_t device;              /* HIP device ordinal; <0 = current device */
+  abd_antigen_obs s;           /* measurement '10222020-S' (abd.py:85) */
+  abd_antigen_obs n;           /* measurement '40588-V08B' (abd.py:94) */
+  const int8_t* vacs;          /* (N, G) row-major 0/1 = TiterData.vacs   (abd.py:114) */
+  const int8_t* pcrpos;        /* (N, G) row-major 0/1 = TiterData.pcrpos (abd.py:115); NULL = ignore_pcrpos (abd.py:416-418) */
+} abd_desc;
+
+typedef struct abd_ctx abd_ctx;
+
+/* Library identity / build info (static string). */
+const char* abd_version(void);
+
+/* Last error message of the calling thread (never NULL). */
+const char* abd_last_error(void);
+
+/* Build a context: validates like the reference (same conditions as abd.py:196-197, 604-622),
+ * sorts + uploads the observation panels, allocates chain slots.  Lazily initialises HIP on first call
+ * in the process (fork-safe: nothing touches the device at load time). */
+int abd_create(const abd_desc* desc, abd_ctx** out);
+int abd_destroy(abd_ctx* ctx);
+
+/* Device description, e.g. "AMD Instinct MI355X gfx950 256 CUs". */
+int abd_device_name(abd_ctx* ctx, char* buf, int32_t buflen);
+
+/* Replace chain slot `chain`'s discrete state: i_raw is (G, N) row-major exactly as PyMC holds the
+ * value variable "i_raw" (dims gap, ind; abd.py:427); waner is (N,) = "ab_s_waner" (abd.py:373).
+ * Values must be 0/1. */
+int abd_set_discrete(abd_ctx* ctx, int32_t chain, const int8_t* i_raw, const int8_t* waner);
+
+/* Flip one bit of the resident discrete state without re-uploading it (what BinaryGibbsMetropolis does
+ * between two logp calls).  flat < G*N addresses i_raw.ravel(); flat >= G*N addresses waner[flat-G*N]. */
+int abd_flip_discrete(abd_ctx* ctx, int32_t chain, int64_t flat);
+
+/* Scalar joint logp at (theta, resident discrete state of `chain`).  Replaces Model.compile_logp()'s
+ * point function (a17). */
+int abd_logp(abd_ctx* ctx, int32_t chain, const double* theta, double* logp);
+
+/* logp and d logp / d theta.  Replaces Model.logp_dlogp_function() (a18). */
+int abd_logp_dlogp(abd_ctx* ctx, int32_t chain, const double* theta, double* logp, double* grad);
+
+/* n evaluations in as few launches as possible: chains[k] in [0, n_chain_slots), theta is n x 17,
+ * logp n, grad n x 17.  The shared OD panels are read once per launch for all chains in it. */
+int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta,
+                         double* logp, double* grad);
+
+/* Stream-ordered form: enqueue returns as soon as the launch is queued; results land in result slot
+ * `slot` (0 <= slot < abd_n_result_slots) and are read back with abd_fetch after abd_wait.
+ * A NUTS driver that runs several chain groups uses this to overlap host work with the device. */
+int abd_n_result_slots(abd_ctx* ctx);
+int abd_logp_dlogp_batch_enqueue(abd_ctx* ctx, int32_t slot, int32_t n, const int32_t* chains,
+                                 const double* theta);
+int abd_wait(abd_ctx* ctx);
+int abd_fetch(abd_ctx* ctx, int32_t slot, double* logp, double* grad);
+
+/* The three recorded Deterministics for chain slot `chain` at theta, each (G, N) row-major as PyMC
+ * stores them (dims gap, ind).  Any output pointer may be NULL. */
+int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t* i, double* ab_n_mu,
+                       double* ab_s_mu);
+
+/* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
+ * events on the context's stream; abd_kernel_time returns the accumulated kernel time and launch count
+ * since the last reset (synchronises the stream). */
+int abd_kernel_timing(abd_ctx* ctx, int32_t enable);
+int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
+
+/* Algorithmic bytes one launch of `n_chains` evaluations has to read:
+ * dense: G*N*(4R + 2 + n_chains) + n_chains*N ; sparse: sum_A K_A*(2R + gap index) + ... */
+int64_t abd_algorithmic_bytes(abd_ctx* ctx, int32_t n_chains);
+
+/* 1 if the observation panels were recognised as dense (one S and one N reading in every cell). */
+int abd_is_dense(abd_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABD_HIP_H */

@@ -1,0 +1,234 @@
+"""
+GPU parity: the HIP path (through the C ABI, via ctypes) against the CPU oracle on the same seeded
+inputs.  Tolerance: 1e-6 relative on fp64 logp and on every gradient entry (north_star); in practice
+the agreement is ~1e-12.  Gradient entries are compared relative to max(|g_k|, 1e-6 * max|g|): an
+entry that cancels to ~0 has no meaningful relative error.
+"""
+import numpy as np
+import pytest
+
+from abdpymc_amd import synthetic
+from oracle import abd_oracle as O
+from tests.helpers import oracle_cohort_from_synth, random_sparse_cohort
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def _ctx(coh, splits=None, ignore=False, n_chains=1, storage="f64"):
+    from abdpymc_amd._native import Context
+
+    return Context(
+        coh.n_gaps,
+        coh.n_inds,
+        (coh.s.idx_gap, coh.s.idx_ind, coh.s.log_dilution, coh.s.od),
+        (coh.n.idx_gap, coh.n.idx_ind, coh.n.log_dilution, coh.n.od),
+        coh.vacs,
+        None if ignore else coh.pcrpos,
+        splits=splits,
+        n_chains=n_chains,
+        storage=storage,
+    )
+
+
+def _state(coh, seed, rate=None):
+    rng = np.random.default_rng(seed)
+    rate = rate if rate is not None else 2.0 / coh.n_gaps
+    i_raw = (rng.random((coh.n_gaps, coh.n_inds)) < rate).astype(np.int8)
+    w = (rng.random(coh.n_inds) < 0.5).astype(np.int8)
+    theta = synthetic.theta_init(coh.n_gaps) + 0.3 * rng.standard_normal(17)
+    return theta, i_raw, w
+
+
+def assert_close(lp, g, lp_ref, g_ref, rtol=RTOL):
+    assert abs(lp - lp_ref) <= rtol * abs(lp_ref), (lp, lp_ref)
+    scale = np.maximum(np.abs(g_ref), 1e-6 * np.abs(g_ref).max())
+    err = np.abs(g - g_ref) / scale
+    assert err.max() <= rtol, (err, g, g_ref)
+
+
+@pytest.mark.parametrize("G,N", [(20, 23), (60, 100), (64, 65), (65, 7), (200, 50), (256, 9), (2, 5)])
+@pytest.mark.parametrize("splits", [None, "one", "two"])
+def test_dense_parity(G, N, splits):
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(N, G, seed=G * 1000 + N))
+    sp = {None: None, "one": (G // 2,), "two": (G // 3, (2 * G) // 3)}[splits]
+    ctx = _ctx(coh, sp)
+    assert ctx.is_dense
+    theta, i_raw, w = _state(coh, 11)
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh, sp)
+    assert_close(lp, g, lp_ref, g_ref)
+    assert abs(ctx.logp(0, theta) - lp_ref) <= RTOL * abs(lp_ref)
+    ctx.close()
+
+
+def test_dense_matches_literal_dense_oracle():
+    """Against the reference-faithful (G,G,N) formulation (abd.py:242-274), small enough to fit."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(40, 31, seed=77))
+    ctx = _ctx(coh, (14, 20))
+    theta, i_raw, w = _state(coh, 5)
+    ctx.set_discrete(0, i_raw, w)
+    lp = ctx.logp(0, theta)
+    ref = O.joint_logp(theta, i_raw, w, coh, (14, 20), dense=True)
+    assert abs(lp - ref) <= RTOL * abs(ref)
+
+
+@pytest.mark.parametrize("ignore", [False, True])
+@pytest.mark.parametrize("splits", [None, (10,), (0,), (26,), (8, 18)])
+def test_sparse_parity(ignore, splits):
+    coh = random_sparse_cohort(37, 26, 900, 700, seed=9)
+    ctx = _ctx(coh, splits, ignore)
+    assert not ctx.is_dense
+    theta, i_raw, w = _state(coh, 12)
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh, splits, ignore)
+    assert_close(lp, g, lp_ref, g_ref)
+
+
+def test_sparse_many_obs_per_individual():
+    """More than 64 observations per individual -> several lane chunks per wave."""
+    coh = random_sparse_cohort(5, 40, 1500, 1100, seed=10)
+    ctx = _ctx(coh)
+    theta, i_raw, w = _state(coh, 13)
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh)
+    assert_close(lp, g, lp_ref, g_ref)
+
+
+def test_empty_antigen_and_individuals_without_obs():
+    coh = random_sparse_cohort(9, 12, 0, 30, seed=2)
+    ctx = _ctx(coh)
+    theta, i_raw, w = _state(coh, 14)
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh)
+    assert_close(lp, g, lp_ref, g_ref)
+
+
+@pytest.mark.parametrize("n_chains", [1, 2, 3, 4, 5, 8, 17])
+def test_batched_chains(n_chains):
+    """Chains share the OD panels in one launch (1, 2 or 4 per wave); each must equal its own eval."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(300, 70, seed=21))
+    sp = (30,)
+    ctx = _ctx(coh, sp, n_chains=n_chains)
+    thetas, refs = [], []
+    for c in range(n_chains):
+        theta, i_raw, w = _state(coh, 100 + c)
+        ctx.set_discrete(c, i_raw, w)
+        thetas.append(theta)
+        refs.append(O.logp_dlogp(theta, i_raw, w, coh, sp))
+    lp, g = ctx.logp_dlogp_batch(np.arange(n_chains), np.array(thetas))
+    for c in range(n_chains):
+        assert_close(lp[c], g[c], *refs[c])
+    # permuted chain order + async path
+    perm = np.arange(n_chains)[::-1].copy()
+    ctx.enqueue(3, perm, np.array(thetas)[perm])
+    ctx.wait()
+    lp2, g2 = ctx.fetch(3, n_chains)
+    np.testing.assert_array_equal(lp2, lp[perm])
+    np.testing.assert_array_equal(g2, g[perm])
+
+
+def test_bitwise_reproducible():
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(500, 100, seed=22))
+    ctx = _ctx(coh)
+    theta, i_raw, w = _state(coh, 15)
+    ctx.set_discrete(0, i_raw, w)
+    a = ctx.logp_dlogp(0, theta)
+    for _ in range(5):
+        b = ctx.logp_dlogp(0, theta)
+        assert a[0] == b[0]
+        np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_heavy_infection_masks():
+    """Dense i_raw (all ones / alternating) exercises the greedy 3-gap recurrence and first-in-chunk."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(70, 130, seed=23))
+    for sp in (None, (50,), (40, 90)):
+        ctx = _ctx(coh, sp)
+        for rate in (1.0, 0.5, 0.0):
+            theta, i_raw, w = _state(coh, 16, rate=rate)
+            ctx.set_discrete(0, i_raw, w)
+            lp, g = ctx.logp_dlogp(0, theta)
+            lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh, sp)
+            assert_close(lp, g, lp_ref, g_ref)
+            i, mun, mus = ctx.deterministics(0, theta)
+            i_ref, mun_ref, mus_ref = O.deterministics(theta, i_raw, w, coh, sp)
+            np.testing.assert_array_equal(i, i_ref)  # integer work: bit-exact
+            np.testing.assert_allclose(mun, mun_ref, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(mus, mus_ref, rtol=1e-12, atol=1e-12)
+        ctx.close()
+
+
+def test_fp32_storage():
+    """fp32-held panels, fp64 arithmetic: equals the oracle run on the fp32-rounded panels."""
+    sc = synthetic.make_cohort(200, 64, seed=24)
+    coh = oracle_cohort_from_synth(sc)
+    ctx = _ctx(coh, storage="f32")
+    theta, i_raw, w = _state(coh, 17)
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    coh32 = O.Cohort(
+        coh.n_gaps, coh.n_inds, coh.vacs, coh.pcrpos,
+        O.AntigenObs(coh.s.idx_gap, coh.s.idx_ind, r32(coh.s.log_dilution), r32(coh.s.od)),
+        O.AntigenObs(coh.n.idx_gap, coh.n.idx_ind, r32(coh.n.log_dilution), r32(coh.n.od)),
+    )
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh32)
+    assert_close(lp, g, lp_ref, g_ref)
+    # and within fp32 rounding of the fp64 panels: tolerance 1e-4 relative, stated
+    lp64, g64 = O.logp_dlogp(theta, i_raw, w, coh)
+    assert abs(lp - lp64) <= 1e-4 * abs(lp64)
+
+
+def test_flip_discrete_matches_reupload():
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(33, 40, seed=25))
+    ctx = _ctx(coh, (20,))
+    theta, i_raw, w = _state(coh, 18)
+    ctx.set_discrete(0, i_raw, w)
+    G, N = coh.n_gaps, coh.n_inds
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        flat = int(rng.integers(0, G * N + N))
+        ctx.flip_discrete(0, flat)
+        if flat < G * N:
+            i_raw.ravel()[flat] ^= 1
+        else:
+            w[flat - G * N] ^= 1
+        ref = O.logp_dlogp(theta, i_raw, w, coh, (20,))[0]
+        assert abs(ctx.logp(0, theta) - ref) <= RTOL * abs(ref)
+
+
+def test_argument_errors():
+    from abdpymc_amd._native import Context
+
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(8, 10, seed=1))
+    with pytest.raises(ValueError, match="ascending"):
+        _ctx(coh, (5, 2))
+    with pytest.raises(ValueError, match="largest split"):
+        _ctx(coh, (11,))
+    with pytest.raises(ValueError, match="not unique"):
+        _ctx(coh, (3, 3))
+    with pytest.raises(ValueError, match="positive"):
+        _ctx(coh, (-1,))
+    ctx = _ctx(coh)
+    with pytest.raises(Exception, match="no discrete state"):
+        ctx.logp(0, synthetic.theta_init(10))
+    with pytest.raises(ValueError):
+        ctx.set_discrete(0, np.full((10, 8), 2, dtype=np.int8), np.zeros(8, dtype=np.int8))
+    with pytest.raises(ValueError):
+        ctx.set_discrete(1, np.zeros((10, 8), dtype=np.int8), np.zeros(8, dtype=np.int8))
+
+
+def test_out_of_support_is_not_an_error():
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(8, 10, seed=1))
+    ctx = _ctx(coh)
+    theta, i_raw, w = _state(coh, 19)
+    ctx.set_discrete(0, i_raw, w)
+    theta[13] = 800.0  # sigma = exp(800) = inf
+    lp, g = ctx.logp_dlogp(0, theta)
+    assert not np.isfinite(lp)

@@ -42,19 +42,21 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int kResultSlots = 1024;
+constexpr int kMinSegLen = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
 struct AntigenDev {
   int64_t K = 0;
-  void* y = nullptr;       // R[K], sorted by (ind, gap)
-  void* x = nullptr;       // R[K]
+  void* y = nullptr;       // sparse: R[K], sorted by (ind, gap)
+  void* x = nullptr;       // sparse: R[K]
   uint8_t* g = nullptr;    // sparse: gap per obs
   int32_t* ptr = nullptr;  // sparse: (N+1)
+  void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
 };
 
 struct ChainSlot {
-  int8_t* iraw_ng = nullptr;  // (N, G)
-  int8_t* waner = nullptr;    // (N)
+  uint64_t* rw = nullptr;   // [nt][N] packed i_raw
+  int8_t* waner = nullptr;  // [N]
   bool set = false;
 };
 
@@ -75,14 +77,18 @@ struct abd_ctx {
   bool ignore_pcr = false;
   int n_slots = 0;
   int n_cu = 256;
-  int blocks_x = 0;
+  int n_lg = 0;           // 64-individual lane groups
+  int blocks_x = 0;       // sparse kernel grid
+  int blocks_max = 0;     // rows per chain in `partials`
+  int cpw_forced = 0;
+  int seg_len_forced = 0;
   uint64_t chunk_mask[3][ABD_MAXT] = {};
   AntigenDev s, n;
-  int8_t* vacs = nullptr;
-  int8_t* pcr = nullptr;
+  uint64_t* vw = nullptr;  // [nt][N]
+  uint64_t* pw = nullptr;  // [nt][N]
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
-  double* partials = nullptr;  // [n_slots][blocks_x][ABD_NOUT]
+  double* partials = nullptr;  // [n_slots][blocks_max][ABD_NOUT]
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   std::vector<ResultSlot> results;
@@ -184,30 +190,34 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
   return lp;
 }
 
-// Combine the device sums of one chain with the host-side terms.
+// Combine the device sums of one chain with the host-side terms.  The device accumulates
+//   Q2 = sum q^2, H.. = sums of h' = q s (1 - s), QS = sum q s   with q = od - d s   (abd_kernels.hpp)
+// so  ll = -1/2 Q2 / sigma^2 - K (log sigma + 1/2 log 2 pi),  d ll / d a_k = -b (d / sigma^2) h'_k.
 void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad) {
   const Transformed tr = transform(t);
   const double n1 = sums[ABD_NACC], m1 = sums[ABD_NACC + 1];
   const double cells = (double)c->G * (double)c->N;
   double lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad);
   const double Kn = (double)c->n.K, Ks = (double)c->s.K;
-  lp += -0.5 * sums[A_N_R2] - Kn * (t[13] + 0.5 * kLog2Pi);
-  lp += -0.5 * sums[A_S_R2] - Ks * (t[16] + 0.5 * kLog2Pi);
+  const double is2_n = 1.0 / (tr.sig_n * tr.sig_n), is2_s = 1.0 / (tr.sig_s * tr.sig_s);
+  lp += -0.5 * is2_n * sums[A_N_Q2] - Kn * (t[13] + 0.5 * kLog2Pi);
+  lp += -0.5 * is2_s * sums[A_S_Q2] - Ks * (t[16] + 0.5 * kLog2Pi);
   *logp = lp;
   if (grad) {
-    grad[1] += -tr.b_n * tr.perm_n * sums[A_N_HC];
-    grad[2] += -tr.b_n * tr.temp_n * sums[A_N_HU];
-    grad[3] += -tr.b_n * tr.temp_n * tr.rho_n * (1.0 - tr.rho_n) * sums[A_N_HD];
-    grad[4] += -tr.b_n * sums[A_N_H];
-    grad[11] += -sums[A_N_HX];
-    grad[12] += sums[A_N_WS];
-    grad[13] += sums[A_N_R2] - Kn;
-    grad[5] += -tr.b_s * tr.perm_s * sums[A_S_HC];
-    grad[6] += -tr.b_s * tr.rho_s * (1.0 - tr.rho_s) * sums[A_S_HD];
-    grad[10] += -tr.b_s * sums[A_S_H];
-    grad[14] += -sums[A_S_HX];
-    grad[15] += sums[A_S_WS];
-    grad[16] += sums[A_S_R2] - Ks;
+    const double fn = -tr.b_n * tr.d_n * is2_n, fs = -tr.b_s * tr.d_s * is2_s;
+    grad[1] += fn * tr.perm_n * sums[A_N_HC];
+    grad[2] += fn * tr.temp_n * sums[A_N_HU];
+    grad[3] += fn * tr.temp_n * tr.rho_n * (1.0 - tr.rho_n) * sums[A_N_HD];
+    grad[4] += fn * sums[A_N_H];
+    grad[11] += -tr.d_n * is2_n * sums[A_N_HX];
+    grad[12] += is2_n * sums[A_N_QS];
+    grad[13] += is2_n * sums[A_N_Q2] - Kn;
+    grad[5] += fs * tr.perm_s * sums[A_S_HC];
+    grad[6] += fs * tr.rho_s * (1.0 - tr.rho_s) * sums[A_S_HD];
+    grad[10] += fs * sums[A_S_H];
+    grad[14] += -tr.d_s * is2_s * sums[A_S_HX];
+    grad[15] += is2_s * sums[A_S_QS];
+    grad[16] += is2_s * sums[A_S_Q2] - Ks;
   }
 }
 
@@ -223,11 +233,9 @@ ChainPar chain_par(const abd_ctx* c, int chain, const double* t) {
   p.init_s = tr.init_s;
   p.b_n = tr.b_n;
   p.d_n = tr.d_n;
-  p.isig_n = 1.0 / tr.sig_n;
   p.b_s = tr.b_s;
   p.d_s = tr.d_s;
-  p.isig_s = 1.0 / tr.sig_s;
-  p.iraw = c->slots[chain].iraw_ng;
+  p.rw = c->slots[chain].rw;
   p.waner = c->slots[chain].waner;
   return p;
 }
@@ -242,51 +250,60 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.g_s = c->s.g;
   a.ptr_n = c->n.ptr;
   a.ptr_s = c->s.ptr;
-  a.vacs = c->vacs;
-  a.pcr = c->ignore_pcr ? nullptr : c->pcr;
+  a.yx_n = c->n.yx;
+  a.yx_s = c->s.yx;
+  a.vw = c->vw;
+  a.pw = c->ignore_pcr ? nullptr : c->pw;
   a.partials = c->partials;
   a.G = c->G;
   a.N = c->N;
   a.nt = c->nt;
   a.n_chunks = c->n_chunks;
+  a.n_lg = c->n_lg;
   std::memcpy(a.chunk_mask, c->chunk_mask, sizeof a.chunk_mask);
 }
 
-size_t eval_lds_bytes(int G, int cpw) {
-  return (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * cpw * ABD_NOUT * sizeof(double);
+size_t table_lds_bytes(int G, int cpw, int red_rows) {
+  return (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double);
 }
 
-template <typename R, int CPW, bool DENSE>
-void launch_eval_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  if (grad)
-    hipLaunchKernelGGL((abd_eval_kernel<R, CPW, DENSE, true>), grid, dim3(ABD_BLOCK), lds, st, a);
-  else
-    hipLaunchKernelGGL((abd_eval_kernel<R, CPW, DENSE, false>), grid, dim3(ABD_BLOCK), lds, st, a);
+template <typename K>
+hipError_t launch_k(K kernel, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(ABD_BLOCK), lds, st, a);
+  return hipGetLastError();
 }
 
-template <typename R, int CPW>
-void launch_eval_d(bool dense, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  if (dense)
-    launch_eval_g<R, CPW, true>(grad, grid, lds, st, a);
-  else
-    launch_eval_g<R, CPW, false>(grad, grid, lds, st, a);
+template <typename R, int C>
+hipError_t launch_dense_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  return grad ? launch_k(abd_dense_kernel<R, C, true>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, C, false>, grid, lds, st, a);
 }
-
 template <typename R>
-void launch_eval_c(int cpw, bool dense, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  switch (cpw) {
-    case 4: launch_eval_d<R, 4>(dense, grad, grid, lds, st, a); break;
-    case 2: launch_eval_d<R, 2>(dense, grad, grid, lds, st, a); break;
-    default: launch_eval_d<R, 1>(dense, grad, grid, lds, st, a); break;
+hipError_t launch_dense(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  switch (C) {
+    case 4: return launch_dense_g<R, 4>(grad, grid, lds, st, a);
+    case 2: return launch_dense_g<R, 2>(grad, grid, lds, st, a);
+    default: return launch_dense_g<R, 1>(grad, grid, lds, st, a);
+  }
+}
+template <typename R, int C>
+hipError_t launch_sparse_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  return grad ? launch_k(abd_sparse_kernel<R, C, true>, grid, lds, st, a) : launch_k(abd_sparse_kernel<R, C, false>, grid, lds, st, a);
+}
+template <typename R>
+hipError_t launch_sparse(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  switch (C) {
+    case 4: return launch_sparse_g<R, 4>(grad, grid, lds, st, a);
+    case 2: return launch_sparse_g<R, 2>(grad, grid, lds, st, a);
+    default: return launch_sparse_g<R, 1>(grad, grid, lds, st, a);
   }
 }
 
-int pick_cpw(int n) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = std::getenv("ABD_CPW");
-    forced = e ? std::atoi(e) : 0;
-  }
+int pick_cpw(const abd_ctx* c, int n) {
+  const int forced = c->cpw_forced;
   if (forced == 1 || forced == 2 || forced == 4) {
     if (n % forced == 0) return forced;
   }
@@ -295,15 +312,43 @@ int pick_cpw(int n) {
   return 1;
 }
 
-// Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH) whose sums go to out rows [row0, row0+n).
+// gaps per segment of the dense kernel for a launch of n chains: enough (lane group, chain, segment)
+// waves to fill the chip ~5 deep, segments no longer than a 64-bit word
+int pick_seg_len(const abd_ctx* c, int n) {
+  const int G = c->G;
+  int len;
+  if (c->seg_len_forced > 0) {
+    len = c->seg_len_forced;
+  } else {
+    const int64_t target_waves = (int64_t)c->n_cu * 4 * 5;
+    const int64_t per_seg = (int64_t)c->n_lg * n;
+    const int64_t n_seg = std::max<int64_t>(1, (target_waves + per_seg - 1) / per_seg);
+    len = (int)((G + n_seg - 1) / n_seg);
+  }
+  return std::max(kMinSegLen, std::min({len, 64, G}));
+}
+
+// Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows) {
   EvalArgs a;
   base_args(c, a);
   a.n_chains = n;
   for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
-  const int cpw = pick_cpw(n);
-  dim3 grid(c->blocks_x, n / cpw);
-  const size_t lds = eval_lds_bytes(c->G, cpw);
+  const int cpw = pick_cpw(c, n);
+  int blocks;
+  size_t lds;
+  if (c->dense) {
+    a.seg_len = pick_seg_len(c, n);
+    a.n_seg = (c->G + a.seg_len - 1) / a.seg_len;
+    const int nsub = ABD_WAVES_PER_BLOCK / cpw;
+    blocks = a.n_seg * ((c->n_lg + nsub - 1) / nsub);
+    lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
+  } else {
+    blocks = c->blocks_x;
+    lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);
+  }
+  if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
+  dim3 grid(blocks, n / cpw);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -317,13 +362,16 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     c->ev_used++;
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
-  if (c->storage == ABD_STORE_F32)
-    launch_eval_c<float>(cpw, c->dense, grad, grid, lds, c->stream, a);
+  hipError_t le;
+  if (c->dense)
+    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, c->stream, a)
+                                     : launch_dense<double>(cpw, grad, grid, lds, c->stream, a);
   else
-    launch_eval_c<double>(cpw, c->dense, grad, grid, lds, c->stream, a);
+    le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, c->stream, a)
+                                     : launch_sparse<double>(cpw, grad, grid, lds, c->stream, a);
   if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(256), 0, c->stream, c->partials, c->blocks_x, d_out_rows);
+  HIP_TRY(le);
+  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(256), 0, c->stream, c->partials, blocks, d_out_rows);
   HIP_TRY(hipGetLastError());
   return ABD_OK;
 }
@@ -368,7 +416,7 @@ int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad) {
   return ABD_OK;
 }
 
-// sort one antigen's observations by (ind, gap); returns false on an out-of-range index
+// one antigen's observations sorted by (ind, gap)
 struct SortedObs {
   std::vector<int64_t> order;  // order[k] = original index
   std::vector<int32_t> ptr;    // (N+1)
@@ -405,7 +453,20 @@ int sort_obs(const abd_antigen_obs& o, int G, int N, const char* tag, SortedObs&
 template <typename R>
 int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, AntigenDev& d) {
   const size_t K = (size_t)o.n_obs;
+  const int G = c->G, N = c->N;
   d.K = o.n_obs;
+  if (c->dense) {
+    // gap-major panel of {od, log_dilution} pairs: element (g, j) at [g * N + j]
+    std::vector<YX<R>> yx((size_t)G * N);
+    for (int j = 0; j < N; ++j)
+      for (int g = 0; g < G; ++g) {
+        const int64_t src = so.order[(size_t)j * G + g];
+        yx[(size_t)g * N + j] = YX<R>{(R)o.od[src], (R)o.log_dilution[src]};
+      }
+    HIP_TRY(hipMalloc(&d.yx, yx.size() * sizeof(YX<R>)));
+    HIP_TRY(hipMemcpy(d.yx, yx.data(), yx.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
+    return ABD_OK;
+  }
   std::vector<R> y(std::max<size_t>(K, 1)), x(std::max<size_t>(K, 1));
   std::vector<uint8_t> g(std::max<size_t>(K, 1));
   for (size_t k = 0; k < K; ++k) {
@@ -418,13 +479,21 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
   HIP_TRY(hipMalloc(&d.x, x.size() * sizeof(R)));
   HIP_TRY(hipMemcpy(d.y, y.data(), y.size() * sizeof(R), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d.x, x.data(), x.size() * sizeof(R), hipMemcpyHostToDevice));
-  if (!c->dense) {
-    HIP_TRY(hipMalloc(&d.g, g.size()));
-    HIP_TRY(hipMemcpy(d.g, g.data(), g.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&d.ptr, so.ptr.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(d.ptr, so.ptr.data(), so.ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
+  HIP_TRY(hipMalloc(&d.g, g.size()));
+  HIP_TRY(hipMemcpy(d.g, g.data(), g.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&d.ptr, so.ptr.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d.ptr, so.ptr.data(), so.ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return ABD_OK;
+}
+
+// (N, G) row-major 0/1 bytes (TiterData.vacs / .pcrpos) -> packed words [nt][N]
+std::vector<uint64_t> pack_ng(const int8_t* src, int G, int N, int nt) {
+  std::vector<uint64_t> w((size_t)nt * N, 0);
+  if (!src) return w;
+  for (int j = 0; j < N; ++j)
+    for (int g = 0; g < G; ++g)
+      if (src[(size_t)j * G + g]) w[(size_t)(g >> 6) * N + j] |= 1ull << (g & 63);
+  return w;
 }
 
 void free_ctx(abd_ctx* c) {
@@ -436,12 +505,13 @@ void free_ctx(abd_ctx* c) {
     if (a->x) (void)hipFree(a->x);
     if (a->g) (void)hipFree(a->g);
     if (a->ptr) (void)hipFree(a->ptr);
+    if (a->yx) (void)hipFree(a->yx);
   }
-  if (c->vacs) (void)hipFree(c->vacs);
-  if (c->pcr) (void)hipFree(c->pcr);
+  if (c->vw) (void)hipFree(c->vw);
+  if (c->pw) (void)hipFree(c->pw);
   if (c->stage_gn) (void)hipFree(c->stage_gn);
   for (auto& s : c->slots) {
-    if (s.iraw_ng) (void)hipFree(s.iraw_ng);
+    if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
   }
   if (c->partials) (void)hipFree(c->partials);
@@ -458,7 +528,7 @@ void free_ctx(abd_ctx* c) {
 
 extern "C" {
 
-const char* abd_version(void) { return "abdpymc_amd hip gfx950 0.1"; }
+const char* abd_version(void) { return "abdpymc_amd hip gfx950 0.2"; }
 
 const char* abd_last_error(void) { return g_err.c_str(); }
 
@@ -496,6 +566,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->G = G;
   c->N = N;
   c->nt = (G + 63) / 64;
+  c->n_lg = (N + 63) / 64;
   c->n_chunks = d->n_splits + 1;
   c->storage = d->storage;
   c->dense = so_s.one_per_cell && so_n.one_per_cell;
@@ -531,9 +602,20 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   snprintf(c->name, sizeof c->name, "%s %s %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
+  // sparse kernel: persistent waves, one individual at a time
   int bpc = 2;
   if (const char* e = std::getenv("ABD_BLOCKS_PER_CU")) bpc = std::max(1, std::atoi(e));
-  c->blocks_x = std::max(1, std::min((N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * bpc));
+  const int sparse_max = std::max(1, std::min((N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 16));
+  c->blocks_x = std::max(1, std::min(sparse_max, c->n_cu * bpc));
+  // dense kernel: one block per (segment, lane group[s]); at most ceil(G / kMinSegLen) segments
+  const int dense_max = ((G + kMinSegLen - 1) / kMinSegLen) * c->n_lg;
+  c->blocks_max = c->dense ? std::max(dense_max, sparse_max) : sparse_max;
+  if (const char* e = std::getenv("ABD_CPW")) c->cpw_forced = std::atoi(e);
+  if (const char* e = std::getenv("ABD_SEG_LEN")) c->seg_len_forced = std::atoi(e);
+  if (table_lds_bytes(G, 4, 16) > 160 * 1024) {
+    free_ctx(c);
+    return fail(ABD_ERR_ARG, "LDS tables for n_gaps=%d do not fit", G);
+  }
 
   if (c->storage == ABD_STORE_F32) {
     rc = upload_antigen<float>(c, d->s, so_s, c->s);
@@ -547,31 +629,27 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     return rc;
   }
   const size_t cells = (size_t)G * N;
-  CREATE_TRY(hipMalloc(&c->vacs, cells));
-  CREATE_TRY(hipMemcpy(c->vacs, d->vacs, cells, hipMemcpyHostToDevice));
-  CREATE_TRY(hipMalloc(&c->pcr, cells));
-  if (d->pcrpos)
-    CREATE_TRY(hipMemcpy(c->pcr, d->pcrpos, cells, hipMemcpyHostToDevice));
-  else
-    CREATE_TRY(hipMemset(c->pcr, 0, cells));
+  const size_t words = (size_t)c->nt * N;
+  {
+    const std::vector<uint64_t> vw = pack_ng(d->vacs, G, N, c->nt);
+    const std::vector<uint64_t> pw = pack_ng(d->pcrpos, G, N, c->nt);
+    CREATE_TRY(hipMalloc(&c->vw, words * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc(&c->pw, words * sizeof(uint64_t)));
+    CREATE_TRY(hipMemcpy(c->vw, vw.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->pw, pw.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   CREATE_TRY(hipMalloc(&c->stage_gn, cells));
   c->slots.resize((size_t)c->n_slots);
   for (auto& s : c->slots) {
-    CREATE_TRY(hipMalloc(&s.iraw_ng, cells));
+    CREATE_TRY(hipMalloc(&s.rw, words * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
   }
-  CREATE_TRY(hipMalloc(&c->partials, (size_t)c->n_slots * c->blocks_x * ABD_NOUT * sizeof(double)));
+  CREATE_TRY(hipMalloc(&c->partials, (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
   const size_t out_bytes = (size_t)kResultSlots * c->n_slots * ABD_NOUT * sizeof(double);
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   c->results.resize(kResultSlots);
-  // the dense kernels with 4 chains per wave need > 64 KB of dynamic LDS only for very large G; ask once
-  const size_t lds_max = eval_lds_bytes(G, 4);
-  if (lds_max > 64 * 1024) {
-    free_ctx(c);
-    return fail(ABD_ERR_ARG, "LDS table for n_gaps=%d does not fit", G);
-  }
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -605,8 +683,8 @@ int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(c->stage_gn, i_raw, cells, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s.waner, waner, (size_t)c->N, hipMemcpyHostToDevice));
-  dim3 grid((c->N + 63) / 64, (c->G + 63) / 64);
-  hipLaunchKernelGGL(abd_transpose_i8_kernel, grid, dim3(256), 0, c->stream, c->stage_gn, s.iraw_ng, c->G, c->N);
+  dim3 grid((c->N + 255) / 256, c->nt);
+  hipLaunchKernelGGL(abd_pack_bits_kernel, grid, dim3(256), 0, c->stream, c->stage_gn, s.rw, c->G, c->N, c->nt);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   s.set = true;
@@ -621,7 +699,7 @@ int abd_flip_discrete(abd_ctx* c, int32_t chain, int64_t flat) {
   if (!c->slots[(size_t)chain].set) return fail(ABD_ERR_STATE, "chain slot %d has no discrete state", chain);
   HIP_TRY(hipSetDevice(c->device));
   ChainSlot& s = c->slots[(size_t)chain];
-  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, s.iraw_ng, s.waner, c->G, c->N, flat);
+  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, s.rw, s.waner, c->G, c->N, flat);
   HIP_TRY(hipGetLastError());
   return ABD_OK;
 }
@@ -672,16 +750,20 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   const size_t cells = (size_t)c->G * c->N;
   int8_t* d_i = nullptr;
   double *d_n = nullptr, *d_s = nullptr;
-  if (i) HIP_TRY(hipMalloc(&d_i, cells));
-  if (mu_n) HIP_TRY(hipMalloc(&d_n, cells * sizeof(double)));
-  if (mu_s) HIP_TRY(hipMalloc(&d_s, cells * sizeof(double)));
-  EvalArgs a;
-  base_args(c, a);
-  a.n_chains = 1;
-  a.ch[0] = chain_par(c, chain, theta);
-  const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
-  hipLaunchKernelGGL(abd_deterministics_kernel, dim3(c->blocks_x), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s);
-  hipError_t e = hipGetLastError();
+  hipError_t e = hipSuccess;
+  if (i) e = hipMalloc(&d_i, cells);
+  if (e == hipSuccess && mu_n) e = hipMalloc(&d_n, cells * sizeof(double));
+  if (e == hipSuccess && mu_s) e = hipMalloc(&d_s, cells * sizeof(double));
+  if (e == hipSuccess) {
+    EvalArgs a;
+    base_args(c, a);
+    a.n_chains = 1;
+    a.ch[0] = chain_par(c, chain, theta);
+    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
+    const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess && i) e = hipMemcpy(i, d_i, cells, hipMemcpyDeviceToHost);
   if (e == hipSuccess && mu_n) e = hipMemcpy(mu_n, d_n, cells * sizeof(double), hipMemcpyDeviceToHost);
@@ -690,6 +772,22 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   if (d_n) (void)hipFree(d_n);
   if (d_s) (void)hipFree(d_s);
   if (e != hipSuccess) return fail(ABD_ERR_HIP, "deterministics: %s", hipGetErrorString(e));
+  return ABD_OK;
+}
+
+int abd_set_launch_config(abd_ctx* c, int32_t blocks, int32_t chains_per_wave) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (!(chains_per_wave == 0 || chains_per_wave == 1 || chains_per_wave == 2 || chains_per_wave == 4))
+    return fail(ABD_ERR_ARG, "chains_per_wave must be 0 (auto), 1, 2 or 4");
+  c->cpw_forced = chains_per_wave;
+  if (blocks > 0 && !c->dense) c->blocks_x = std::max(1, std::min(blocks, c->blocks_max));
+  return ABD_OK;
+}
+
+int abd_set_segment_length(abd_ctx* c, int32_t seg_len) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (seg_len < 0 || seg_len > 64) return fail(ABD_ERR_ARG, "segment length must be 0 (auto) or in [1, 64]");
+  c->seg_len_forced = seg_len;
   return ABD_OK;
 }
 
@@ -723,9 +821,10 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   if (!c) return 0;
   const int64_t R = c->storage == ABD_STORE_F32 ? 4 : 8;
   const int64_t cells = (int64_t)c->G * c->N;
-  if (c->dense) return cells * (4 * R + 2 + n_chains) + (int64_t)n_chains * c->N;
-  // sparse: per observation od + log_dilution + gap index (held as 1 byte), CSR pointers, three indicator panels
-  return (c->s.K + c->n.K) * (2 * R + 1) + 2 * (int64_t)(c->N + 1) * 4 + cells * (2 + n_chains) + (int64_t)n_chains * c->N;
+  // indicator panels are bit-packed in 64-gap words: vacs + pcrpos + one i_raw per chain, plus the waner bytes
+  const int64_t bits = (int64_t)c->nt * c->N * 8 * (2 + n_chains) + (int64_t)n_chains * c->N;
+  if (c->dense) return cells * 4 * R + bits;
+  return (c->s.K + c->n.K) * (2 * R + 1) + 2 * (int64_t)(c->N + 1) * 4 + bits;
 }
 
 }  // extern "C"

@@ -2,75 +2,90 @@
 //
 // What the reference computes per evaluation (abdpymc/abd.py) and how it is mapped here:
 //
-//   i = constrain(i_raw, pcrpos)          abd.py:640-667, 560-601, 732-818   -> wave-uniform 64-bit masks
-//   perm_response / temp responses         abd.py:242-306                     -> closed form over set bits
+//   i = constrain(i_raw, pcrpos)          abd.py:640-667, 560-601, 732-818   -> 64-bit words, bit b of word w = gap 64 w + b
+//   perm_response / temp responses         abd.py:242-306                     -> recurrence (abd.py:277-293) inside a gap
+//                                                                               segment, closed form (abd.py:258-274) to enter it
 //   mu[idx_gap, idx_ind] -> logistic -> N  abd.py:343, 393, 445-469, 556-557  -> per-lane fp64, register sums
 //
-// One 64-lane wavefront owns one individual at a time; the lanes run along the gap axis (the panels are
-// held individual-major, (N, G), so a wave's loads are contiguous).  The individual's three indicator
-// rows (i_raw, pcrpos, vacs) are turned into 64-bit masks with one v_cmp per 64 gaps (ballot), so the
-// whole integer pre-pass -- one-infection-per-chunk, PCR+ precedence, the 3-gap refractory recurrence on
-// its own output -- runs on the scalar unit on <= 4 words.
+// Indicator panels (i_raw per chain, pcrpos, vacs) are held bit-packed, one 64-bit word per individual
+// per 64 gaps, laid out [word][individual].
 //
-// The reference's dense decay design, out[c] = sum_r (rho^max(0,c-r) - [c<r]) e[r]  (abd.py:258-274),
-// is evaluated literally as a sum over the (few) set bits r <= c of the exposure mask, with rho^k and
-// k rho^(k-1) read from a per-block LDS table -- no (G,G,N) tensor and no sequential scan.
+// Dense panels (benchmark configs; exactly one S and one N reading per cell): the OD panels are held
+// gap-major, (G, N) arrays of [od, log_dilution] pairs -- the reference's own (gap, ind) orientation.
+// A LANE owns one individual and walks a segment of consecutive gaps, so a wave's load of one gap row is
+// 64 contiguous pairs (1 KiB), there is no cross-lane traffic until the final reduction, and no lane is
+// idle whatever G is.  Work item = (64 individuals, chain, gap segment); the state a segment starts from
+// (titer responses, their rho-sensitivities, exposure flags) is rebuilt per lane from the packed words:
+// constrain on the words, then the reference's dense design summed over the set bits before the segment
+// with rho^k read from an LDS table.  The 4 waves of a workgroup are 4 chains of the same item, so the
+// panel rows they share are fetched from HBM once and served from L1/L2 to the others.
 //
-// Sums over individuals x gaps stay in registers for the life of the wave (grid-stride over
-// individuals), are reduced once per wave, once per block through LDS, written as per-block partials
-// and summed in a fixed order by a second tiny kernel: no float atomics, bit-reproducible.
+// Sparse observation lists (the real cohorts): one wave per individual, lanes over its observations
+// (CSR by individual), same masks, responses by the closed form.
+//
+// Sums stay in registers, are reduced once per wave (halving butterfly), once per block through LDS,
+// written as per-block partials and summed in a fixed order by a second tiny kernel: no float atomics,
+// bit-reproducible for a given launch shape.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define ABD_MAXT 4          // 64-gap tiles per individual (G <= 256)
+#define ABD_MAXT 4          // 64-gap words per individual (G <= 256)
 #define ABD_NACC 13         // floating sums per chain (see enum below)
 #define ABD_NOUT 16         // ABD_NACC + n1 + m1, padded
 #define ABD_MAX_BATCH_K 16  // chains per launch
 #define ABD_WAVES_PER_BLOCK 4
 #define ABD_BLOCK (64 * ABD_WAVES_PER_BLOCK)
 
-// raw sums accumulated on the device; constants (-b, perm, rho(1-rho) ...) are applied on the host
+// raw sums accumulated on the device; per-chain constants are applied on the host (abd_capi.hip: assemble)
+//   q = od - d s,  s = 1 / (1 + exp(b (a - x))),  h' = q s (1 - s)
+//   d ll / d a = -b (d / sigma^2) h'
 enum {
-  A_N_R2 = 0,   // sum r^2                       (N likelihood)
-  A_N_H,        // sum h            -> init_n    h = (r/sigma) d s (1-s);  d ll/d a = -b h
-  A_N_HC,       // sum h [cumI>0]   -> perm_n
-  A_N_HU,       // sum h U_n        -> temp_n    U_n = sum_r rho_n^(g-r)
-  A_N_HD,       // sum h dU_n/drho  -> rho_n
-  A_N_HX,       // sum h (a - x)    -> b_n
-  A_N_WS,       // sum (r/sigma) s  -> d_n
-  A_S_R2,
+  A_N_Q2 = 0,   // sum q^2                        -> ll, d/d log sigma
+  A_N_H,        // sum h'            -> init_n
+  A_N_HC,       // sum h' [cumI>0]   -> perm_n
+  A_N_HU,       // sum h' U_n        -> temp_n    U_n = sum_r rho_n^(g-r)
+  A_N_HD,       // sum h' dU_n/drho  -> rho_n
+  A_N_HX,       // sum h' (a - x)    -> b_n
+  A_N_QS,       // sum q s           -> d_n
+  A_S_Q2,
   A_S_H,
   A_S_HC,
   A_S_HD,
   A_S_HX,
-  A_S_WS,
+  A_S_QS,
 };
 
 struct ChainPar {
   double perm_n, temp_n, rho_n, init_n;
   double perm_s, rho_s, init_s;
-  double b_n, d_n, isig_n;
-  double b_s, d_s, isig_s;
-  const int8_t* iraw;   // (N, G) individual-major device copy of the chain's i_raw
-  const int8_t* waner;  // (N,)
+  double b_n, d_n;
+  double b_s, d_s;
+  const uint64_t* rw;   // [nt][N] packed i_raw of the chain
+  const int8_t* waner;  // [N]
 };
 
 struct EvalArgs {
-  const void* y_n;  // od, antigen N            R[K_n]   (dense: K = N*G, k = j*G + g)
-  const void* x_n;  // log_dilution, antigen N
+  // sparse observation lists (CSR by individual)
+  const void* y_n;
+  const void* x_n;
   const void* y_s;
   const void* x_s;
-  const uint8_t* g_n;  // sparse only: gap index of each observation
+  const uint8_t* g_n;
   const uint8_t* g_s;
-  const int32_t* ptr_n;  // sparse only: CSR row pointers by individual, (N+1)
+  const int32_t* ptr_n;
   const int32_t* ptr_s;
-  const int8_t* vacs;  // (N, G)
-  const int8_t* pcr;   // (N, G) or nullptr (ignore_pcrpos)
-  double* partials;    // [n_chains][n_blocks_x][ABD_NOUT]
+  // dense panels, gap-major [G][N] of {od, log_dilution}
+  const void* yx_n;
+  const void* yx_s;
+  // packed indicator panels [nt][N]
+  const uint64_t* vw;
+  const uint64_t* pw;  // nullptr = ignore_pcrpos
+  double* partials;    // [n_chains][grid.x][ABD_NOUT]
   int32_t G, N, nt, n_chunks;
-  int32_t n_chains, pad_;
+  int32_t n_chains, seg_len;  // dense: gaps per segment (<= 64)
+  int32_t n_seg, n_lg;        // dense: segments per individual, 64-individual lane groups
   uint64_t chunk_mask[3][ABD_MAXT];
   ChainPar ch[ABD_MAX_BATCH_K];
 };
@@ -79,15 +94,48 @@ struct double2_t {
   double x, y;
 };
 
+template <typename R>
+struct YX {
+  R y, x;
+};
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
-// Fill one power table: tab[0] = {0,0} (index for "exposure is in the future"), tab[k+1] = {rho^k, k rho^(k-1)}.
-__device__ __forceinline__ void fill_pow_table(double2_t* tab, double rho, int G, int tid, int nthreads) {
-  for (int e = tid; e <= G; e += nthreads) {
+// Sum 16 per-lane values over the 64 lanes with a halving butterfly: after it, lane l with (l & 3) == 0
+// holds the total of value index 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l).  15 + 2 exchanges instead of 96.
+template <int OFF, int HALF>
+__device__ __forceinline__ void reduce16_step(double (&v)[16], int lane) {
+  // compile-time indices only: a runtime-indexed register array becomes a 16-way select network
+  const bool up = (lane & OFF) != 0;
+#pragma unroll
+  for (int k = 0; k < HALF; ++k) {
+    const double send = up ? v[k] : v[k + HALF];
+    const double keep = up ? v[k + HALF] : v[k];
+    v[k] = keep + __shfl_xor(send, OFF, 64);
+  }
+}
+__device__ __forceinline__ double wave_reduce16(double (&v)[16], int lane) {
+  reduce16_step<32, 8>(v, lane);
+  reduce16_step<16, 4>(v, lane);
+  reduce16_step<8, 2>(v, lane);
+  reduce16_step<4, 1>(v, lane);
+  double r = v[0];
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+__device__ __forceinline__ int reduce16_index(int lane) {
+  return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
+// Fill one power table of n_entries: tab[0] = {0,0} (index for "exposure is in the future"),
+// tab[k+1] = {rho^k, k rho^(k-1)}.
+__device__ __forceinline__ void fill_pow_table(double2_t* tab, double rho, int n_entries, int tid, int nthreads) {
+  for (int e = tid; e < n_entries; e += nthreads) {
     double2_t v;
     if (e == 0) {
       v.x = 0.0;
@@ -114,8 +162,18 @@ __device__ __forceinline__ void fill_pow_table(double2_t* tab, double rho, int G
   }
 }
 
-// Wave-uniform integer pre-pass for one individual and one chain (abd.py:640-667).
-//   raw/pcr : masks of i_raw / pcrpos, bit b of word t <-> gap 64 t + b
+__device__ __forceinline__ void fill_ones_table(double2_t* tab, int n_entries, int tid, int nthreads) {
+  for (int e = tid; e < n_entries; e += nthreads) {
+    double2_t v;
+    v.x = e == 0 ? 0.0 : 1.0;  // non-waners: rho_j = 1 (abd.py:374), d rho_j / d rho_s = 0
+    v.y = 0.0;
+    tab[e] = v;
+  }
+}
+
+// Integer pre-pass for one individual and one chain (abd.py:640-667) on packed words.  Works equally on
+// wave-uniform values (sparse kernel: scalar unit) and on per-lane values (dense kernel).
+//   raw/pcr : words of i_raw / pcrpos, bit b of word t <-> gap 64 t + b
 //   out     : the Deterministic "i"
 __device__ __forceinline__ void constrain_masks(const uint64_t raw[ABD_MAXT], const uint64_t pcr[ABD_MAXT],
                                                 const EvalArgs& a, uint64_t out[ABD_MAXT]) {
@@ -170,14 +228,243 @@ __device__ __forceinline__ double ld(const void* p, int64_t k) {
   return (double)reinterpret_cast<const R*>(p)[k];
 }
 
-// Response state of one lane at gap g for one chain.
+// exp(x) for x <= 708 (callers clamp): Cody-Waite reduction by ln 2, degree-12 Taylor on
+// |f| <= ln2/2 (truncation 1.7e-16 relative), scale by 2^k.  17 VALU, no special-case branches.
+__device__ __forceinline__ double exp_reduced(double x) {
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double f = fma(k, -6.93147180369123816490e-01, x);
+  f = fma(k, -1.90821492927058770002e-10, f);
+  double p = 2.08767569878680989792e-09;            // 1/12!
+  p = fma(p, f, 2.50521083854417187751e-08);        // 1/11!
+  p = fma(p, f, 2.75573192239858906526e-07);        // 1/10!
+  p = fma(p, f, 2.75573192239858906526e-06);        // 1/9!
+  p = fma(p, f, 2.48015873015873015873e-05);        // 1/8!
+  p = fma(p, f, 1.98412698412698412698e-04);        // 1/7!
+  p = fma(p, f, 1.38888888888888888889e-03);        // 1/6!
+  p = fma(p, f, 8.33333333333333333333e-03);        // 1/5!
+  p = fma(p, f, 4.16666666666666666667e-02);        // 1/4!
+  p = fma(p, f, 1.66666666666666666667e-01);        // 1/3!
+  p = fma(p, f, 0.5);
+  p = fma(p, f, 1.0);
+  p = fma(p, f, 1.0);
+  return ldexp(p, (int)k);
+}
+
+// 1/d for d in [1, 2^1023): v_rcp_f64 seed + two Newton steps (relative error ~1e-16).
+__device__ __forceinline__ double rcp_newton(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+// One observation of one antigen: logistic curve (abd.py:556-557), residual of the Normal log-term
+// (abd.py:459-469) and its raw gradient sums.  a: inflection titer at this (gap, ind); x: log_dilution; y: od.
+template <bool GRAD>
+__device__ __forceinline__ void obs_term(double a, double x, double y, double b, double d, double guard, double& q2,
+                                         double& sh, double& shx, double& sqs, double& h_out) {
+  const double amx = a - x;
+  const double u = fmin(b * amx, 708.0);   // -b (x - a); exp stays finite, the curve is ~1e-308 there anyway
+  const double e = exp_reduced(u);
+  const double s = rcp_newton(1.0 + e);    // logistic / d
+  const double q = fma(-d, s, y) * guard;  // guard = 0 on padding lanes, else 1
+  q2 = fma(q, q, q2);
+  if (GRAD) {
+    const double h = q * (s * (e * s));    // 1 - s = e s
+    sh += h;
+    shx = fma(h, amx, shx);
+    sqs = fma(q, s, sqs);
+    h_out = h;
+  }
+}
+
+// ================================================================================================
+// Dense-panel kernel: lane = individual, wave = (64 individuals, chain, gap segment)
+// ================================================================================================
+
+// bits [g0, g0 + len) of the packed row, moved to bit 0 (len <= 64; g0 wave-uniform).  Every word is
+// visited with a compile-time index (a runtime-indexed register array would go to scratch).
+__device__ __forceinline__ uint64_t extract_bits(const uint64_t w[ABD_MAXT], int g0, int len) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    const int sh = g0 - t * 64;  // wave-uniform
+    if (sh >= 0 && sh < 64) v |= w[t] >> sh;
+    if (sh < 0 && sh > -64) v |= w[t] << (-sh);
+  }
+  return len >= 64 ? v : (v & ((1ull << len) - 1ull));
+}
+
+template <typename R, int CB, bool GRAD>
+__global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) {
+  // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int G = a.G, N = a.N, nt = a.nt;
+  const int tstride = G + 1;
+  double2_t* tabs = reinterpret_cast<double2_t*>(smem);
+  double2_t* tab_ones = tabs + CB * 2 * tstride;
+  double* red = reinterpret_cast<double*>(tab_ones + tstride);  // [WAVES][ABD_NOUT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NSUB = ABD_WAVES_PER_BLOCK / CB;  // lane groups per block
+  const int c = wave % CB;                        // this wave's chain within the block's group
+  const int sub = wave / CB;
+  const int cbase = blockIdx.y * CB;
+  const ChainPar& p = a.ch[cbase + c];
+
+  const int n_lgb = (a.n_lg + NSUB - 1) / NSUB;
+  const int seg = blockIdx.x / n_lgb;             // lane-group index fastest: neighbours in time are
+  const int lg = (blockIdx.x % n_lgb) * NSUB + sub;  // neighbours in every gap row
+  const int g0 = seg * a.seg_len;
+  const int len = min(a.seg_len, G - g0);
+  const bool wave_on = lg < a.n_lg;
+  const int j_raw = lg * 64 + lane;
+  const bool active = wave_on && j_raw < N;
+  const int j = active ? j_raw : N - 1;
+
+  // power tables up to the exponents a segment start can need (k < g0)
+  const int n_entries = g0 + 1;
+  if (g0 > 0) {
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      fill_pow_table(tabs + (cc * 2 + 0) * tstride, a.ch[cbase + cc].rho_n, n_entries, tid, ABD_BLOCK);
+      fill_pow_table(tabs + (cc * 2 + 1) * tstride, a.ch[cbase + cc].rho_s, n_entries, tid, ABD_BLOCK);
+    }
+    fill_ones_table(tab_ones, n_entries, tid, ABD_BLOCK);
+  }
+
+  // ---- packed indicator rows of this lane's individual; constrain (abd.py:640-667) ----
+  uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+#pragma unroll
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    V[t] = P[t] = Rw[t] = 0;
+    if (t < nt) {
+      V[t] = a.vw[(int64_t)t * N + j];
+      if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
+      Rw[t] = p.rw[(int64_t)t * N + j];
+    }
+  }
+  const bool wj = p.waner[j] != 0;
+  constrain_masks(Rw, P, a, I);
+
+  double acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+  if (seg == 0 && active) {
+    int n1 = 0;
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) n1 += __builtin_popcountll(Rw[t]);  // Bernoulli(i_raw | p) is on the RAW matrix
+    acc[ABD_NACC] = (double)n1;
+    acc[ABD_NACC + 1] = wj ? 1.0 : 0.0;
+  }
+
+  // ---- state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures ----
+  double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
+  bool cum_i = false, cum_iv = false;
+  __syncthreads();
+  if (g0 > 0) {
+    const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
+    const double2_t* tab_s = wj ? tabs + (c * 2 + 1) * tstride : tab_ones;
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) {
+      if (t * 64 < g0) {
+        const int rel = g0 - t * 64;  // bits < rel of word t are before the segment
+        const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
+        uint64_t mi = I[t] & below, mv = V[t] & below;
+        cum_i |= mi != 0;
+        cum_iv |= (mi | mv) != 0;
+        while (mi) {  // per-lane trip count
+          const int b = __builtin_ctzll(mi);
+          mi &= mi - 1;
+          const int idx = g0 - (t * 64 + b);  // = k + 1 with k = (g0 - 1) - r
+          const double2_t pn = tab_n[idx];
+          const double2_t ps = tab_s[idx];
+          tn += pn.x;
+          dn += pn.y;
+          ts += ps.x;
+          ds += ps.y;
+        }
+        while (mv) {
+          const int b = __builtin_ctzll(mv);
+          mv &= mv - 1;
+          const double2_t ps = tab_s[g0 - (t * 64 + b)];
+          ts += ps.x;
+          ds += ps.y;
+        }
+      }
+    }
+  }
+
+  // ---- walk the segment: recurrence form (abd.py:288) + likelihood terms ----
+  const uint64_t seg_i = extract_bits(I, g0, len);
+  const uint64_t seg_v = extract_bits(V, g0, len);
+  const double rho_n = p.rho_n, temp_n = p.temp_n;
+  const double rho_j = wj ? p.rho_s : 1.0;                        // abd.py:374
+  const double base_n0 = p.init_n, base_n1 = p.init_n + p.perm_n; // perm after the first infection   abd.py:306, 330
+  const double base_s0 = p.init_s, base_s1 = p.init_s + p.perm_s; // ... first infection or vaccination abd.py:368
+  const double b_n = p.b_n, d_n = p.d_n, b_s = p.b_s, d_s = p.d_s;
+  const double guard = active ? 1.0 : 0.0;
+  const YX<R>* yxn = reinterpret_cast<const YX<R>*>(a.yx_n) + (int64_t)g0 * N + j;
+  const YX<R>* yxs = reinterpret_cast<const YX<R>*>(a.yx_s) + (int64_t)g0 * N + j;
+  double hd_s = 0.0;
+
+  if (wave_on) {
+#pragma unroll 2
+    for (int gi = 0; gi < len; ++gi) {
+      const YX<R> on = yxn[(int64_t)gi * N];
+      const YX<R> os = yxs[(int64_t)gi * N];
+      const bool ib = (seg_i >> gi) & 1ull;
+      const bool vb = (seg_v >> gi) & 1ull;
+      dn = fma(rho_n, dn, tn);
+      tn = fma(rho_n, tn, ib ? 1.0 : 0.0);
+      ds = fma(rho_j, ds, ts);
+      ts = fma(rho_j, ts, (ib ? 1.0 : 0.0) + (vb ? 1.0 : 0.0));  // unit boosts: temp unused (abd.py:272)
+      cum_i |= ib;
+      cum_iv |= ib | vb;
+      // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
+      const double an = fma(temp_n, tn, cum_i ? base_n1 : base_n0);
+      const double as = (cum_iv ? base_s1 : base_s0) + ts;
+      double h = 0.0;
+      obs_term<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, guard, acc[A_N_Q2], acc[A_N_H], acc[A_N_HX], acc[A_N_QS], h);
+      if (GRAD) {
+        acc[A_N_HC] += cum_i ? h : 0.0;
+        acc[A_N_HU] = fma(h, tn, acc[A_N_HU]);
+        acc[A_N_HD] = fma(h, dn, acc[A_N_HD]);
+      }
+      obs_term<GRAD>(as, (double)os.x, (double)os.y, b_s, d_s, guard, acc[A_S_Q2], acc[A_S_H], acc[A_S_HX], acc[A_S_QS], h);
+      if (GRAD) {
+        acc[A_S_HC] += cum_iv ? h : 0.0;
+        hd_s = fma(h, ds, hd_s);
+      }
+    }
+  }
+  acc[A_S_HD] = wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
+
+  // ---- reduction: lanes -> wave -> block (LDS) -> per-block partial in global memory ----
+  const double tot = wave_reduce16(acc, lane);
+  if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
+  __syncthreads();
+  if (tid < CB * ABD_NOUT) {
+    const int cc = tid / ABD_NOUT, k = tid % ABD_NOUT;
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
+    a.partials[((int64_t)(cbase + cc) * gridDim.x + blockIdx.x) * ABD_NOUT + k] = v;
+  }
+}
+
+// ================================================================================================
+// Sparse-list kernel (the real cohorts: several dilutions per serum sample, most cells empty)
+// ================================================================================================
+
 struct Resp {
   double un, dn, us, ds;
   bool cum_i, cum_iv;
 };
 
 // sum over exposures r <= g of rho^(g-r) (and derivative), literal abd.py:258-274 restricted to set bits.
-// tmax: number of 64-gap words to scan (wave-uniform); g: this lane's gap.
 __device__ __forceinline__ Resp responses(int g, int tmax, const uint64_t I[ABD_MAXT], const uint64_t V[ABD_MAXT],
                                           const double2_t* tab_n, const double2_t* tab_s) {
   Resp r;
@@ -220,33 +507,19 @@ __device__ __forceinline__ Resp responses(int g, int tmax, const uint64_t I[ABD_
   return r;
 }
 
-// One observation of one antigen: logistic curve + Normal log-term + its raw gradient sums.
-//   a: inflection titer at this lane's (gap, ind); x: log_dilution; y: od     abd.py:459-469, 556-557
-template <bool GRAD>
-__device__ __forceinline__ void obs_term(double a, double x, double y, double b, double d, double isig,
-                                         double& r2, double& sh, double& shx, double& sws, double& h_out) {
-  const double amx = a - x;
-  const double u = b * amx;               // -b (x - a)
-  const double e = exp(u);
-  const double s = 1.0 / (1.0 + e);       // logistic / d
-  const double r = (y - d * s) * isig;
-  r2 = fma(r, r, r2);
-  if (GRAD) {
-    const double w = r * isig;            // d ll / d m
-    const double oms = e * s;             // 1 - s
-    const double h = (w * d) * (s * oms);
-    sh += h;
-    shx = fma(h, amx, shx);
-    sws = fma(w, s, sws);
-    h_out = h;
-  }
+// wave-uniform load of one packed word
+__device__ __forceinline__ uint64_t uniform_word(const uint64_t* p, int64_t idx) {
+  const uint64_t v = p[idx];
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
 }
 
-template <typename R, int CPW, bool DENSE, bool GRAD>
-__global__ __launch_bounds__(ABD_BLOCK) void abd_eval_kernel(const EvalArgs a) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  // LDS: [CPW][2][G+1] power tables + [G+1] "ones" table (non-waners: rho_j = 1) + block reduction
-  double2_t* tabs = reinterpret_cast<double2_t*>(smem_raw);
+template <typename R, int CPW, bool GRAD>
+__global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  // LDS: [CPW][2][G+1] power tables + [G+1] "ones" table + block reduction
+  double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   const int G = a.G;
   const int N = a.N;
   const int nt = a.nt;
@@ -261,15 +534,10 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_eval_kernel(const EvalArgs a) {
 
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
-    fill_pow_table(tabs + (c * 2 + 0) * tstride, a.ch[cbase + c].rho_n, G, tid, ABD_BLOCK);
-    fill_pow_table(tabs + (c * 2 + 1) * tstride, a.ch[cbase + c].rho_s, G, tid, ABD_BLOCK);
+    fill_pow_table(tabs + (c * 2 + 0) * tstride, a.ch[cbase + c].rho_n, tstride, tid, ABD_BLOCK);
+    fill_pow_table(tabs + (c * 2 + 1) * tstride, a.ch[cbase + c].rho_s, tstride, tid, ABD_BLOCK);
   }
-  for (int e = tid; e <= G; e += ABD_BLOCK) {
-    double2_t v;
-    v.x = e == 0 ? 0.0 : 1.0;
-    v.y = 0.0;
-    tab_ones[e] = v;
-  }
+  fill_ones_table(tab_ones, tstride, tid, ABD_BLOCK);
   __syncthreads();
 
   double acc[CPW][ABD_NACC];
@@ -283,9 +551,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_eval_kernel(const EvalArgs a) {
 
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
-    // ---- integer pre-pass: indicator rows -> masks (ballot), constrain on the scalar unit ----
     uint64_t V[ABD_MAXT], P[ABD_MAXT], I[CPW][ABD_MAXT];
-    const int64_t row = (int64_t)j * G;
     {
       uint64_t Rw[CPW][ABD_MAXT];
 #pragma unroll
@@ -295,109 +561,61 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_eval_kernel(const EvalArgs a) {
 #pragma unroll
         for (int c = 0; c < CPW; ++c) Rw[c][t] = 0;
         if (t < nt) {
-          const int g = t * 64 + lane;
-          const bool in = g < G;
-          const int8_t vb = in ? a.vacs[row + g] : 0;
-          const int8_t pb = (in && a.pcr) ? a.pcr[row + g] : 0;
-          V[t] = __ballot(vb != 0);
-          P[t] = __ballot(pb != 0);
+          V[t] = uniform_word(a.vw, (int64_t)t * N + j);
+          if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
 #pragma unroll
-          for (int c = 0; c < CPW; ++c) {
-            const int8_t rb = in ? a.ch[cbase + c].iraw[row + g] : 0;
-            Rw[c][t] = __ballot(rb != 0);
-          }
+          for (int c = 0; c < CPW; ++c) Rw[c][t] = uniform_word(a.ch[cbase + c].rw, (int64_t)t * N + j);
         }
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         constrain_masks(Rw[c], P, a, I[c]);
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) n1[c] += __builtin_popcountll(Rw[c][t]);  // Bernoulli(i_raw|p) is on the RAW matrix
+        for (int t = 0; t < ABD_MAXT; ++t) n1[c] += __builtin_popcountll(Rw[c][t]);
       }
     }
     int wj[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
-      wj[c] = a.ch[cbase + c].waner[j] != 0;
+      wj[c] = __builtin_amdgcn_readfirstlane((int)a.ch[cbase + c].waner[j]) != 0;
       m1[c] += wj[c];
     }
 
-    if (DENSE) {
-      // ---- dense panel: one S and one N reading per cell, k = j*G + g ----
-      for (int t = 0; t < nt; ++t) {
-        const int g = t * 64 + lane;
-        const bool in = g < G;
-        const int64_t k = row + (in ? g : 0);
-        const double yn = ld<R>(a.y_n, k), xn = ld<R>(a.x_n, k);
-        const double ys = ld<R>(a.y_s, k), xs = ld<R>(a.x_s, k);
+#pragma unroll
+    for (int ag = 0; ag < 2; ++ag) {
+      const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
+      const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
+      const void* yy = ag == 0 ? a.y_n : a.y_s;
+      const void* xx = ag == 0 ? a.x_n : a.x_s;
+      const int k0 = ptr[j], k1 = ptr[j + 1];
+      for (int kb = k0; kb < k1; kb += 64) {
+        const int k = kb + lane;
+        const bool in = k < k1;
+        const int kk = in ? k : k0;
+        const int g = gi[kk];
+        const double y = ld<R>(yy, kk), x = ld<R>(xx, kk);
+        const double guard = in ? 1.0 : 0.0;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
           const ChainPar& p = a.ch[cbase + c];
           const double2_t* tn = tabs + (c * 2 + 0) * tstride;
           const double2_t* ts = wj[c] ? tabs + (c * 2 + 1) * tstride : tab_ones;
-          const Resp rs = responses(g, t + 1, I[c], V, tn, ts);
-          if (in) {
-            // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
+          const Resp rs = responses(g, nt, I[c], V, tn, ts);
+          double h = 0.0;
+          if (ag == 0) {
             const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-            const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
-            double h = 0.0;
-            obs_term<GRAD>(an, xn, yn, p.b_n, p.d_n, p.isig_n, acc[c][A_N_R2], acc[c][A_N_H], acc[c][A_N_HX],
-                           acc[c][A_N_WS], h);
+            obs_term<GRAD>(an, x, y, p.b_n, p.d_n, guard, acc[c][A_N_Q2], acc[c][A_N_H], acc[c][A_N_HX], acc[c][A_N_QS], h);
             if (GRAD) {
               acc[c][A_N_HC] += rs.cum_i ? h : 0.0;
               acc[c][A_N_HU] = fma(h, rs.un, acc[c][A_N_HU]);
               acc[c][A_N_HD] = fma(h, rs.dn, acc[c][A_N_HD]);
             }
-            obs_term<GRAD>(as, xs, ys, p.b_s, p.d_s, p.isig_s, acc[c][A_S_R2], acc[c][A_S_H], acc[c][A_S_HX],
-                           acc[c][A_S_WS], h);
+          } else {
+            const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
+            obs_term<GRAD>(as, x, y, p.b_s, p.d_s, guard, acc[c][A_S_Q2], acc[c][A_S_H], acc[c][A_S_HX], acc[c][A_S_QS], h);
             if (GRAD) {
               acc[c][A_S_HC] += rs.cum_iv ? h : 0.0;
               acc[c][A_S_HD] = fma(h, rs.ds, acc[c][A_S_HD]);
-            }
-          }
-        }
-      }
-    } else {
-      // ---- sparse observation lists, CSR by individual (the real cohorts; abd.py:343, 393) ----
-#pragma unroll
-      for (int ag = 0; ag < 2; ++ag) {
-        const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
-        const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
-        const void* yy = ag == 0 ? a.y_n : a.y_s;
-        const void* xx = ag == 0 ? a.x_n : a.x_s;
-        const int k0 = ptr[j], k1 = ptr[j + 1];
-        for (int kb = k0; kb < k1; kb += 64) {
-          const int k = kb + lane;
-          const bool in = k < k1;
-          const int kk = in ? k : k0;
-          const int g = gi[kk];
-          const double y = ld<R>(yy, kk), x = ld<R>(xx, kk);
-#pragma unroll
-          for (int c = 0; c < CPW; ++c) {
-            const ChainPar& p = a.ch[cbase + c];
-            const double2_t* tn = tabs + (c * 2 + 0) * tstride;
-            const double2_t* ts = wj[c] ? tabs + (c * 2 + 1) * tstride : tab_ones;
-            const Resp rs = responses(g, nt, I[c], V, tn, ts);
-            if (in) {
-              double h = 0.0;
-              if (ag == 0) {
-                const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-                obs_term<GRAD>(an, x, y, p.b_n, p.d_n, p.isig_n, acc[c][A_N_R2], acc[c][A_N_H], acc[c][A_N_HX],
-                               acc[c][A_N_WS], h);
-                if (GRAD) {
-                  acc[c][A_N_HC] += rs.cum_i ? h : 0.0;
-                  acc[c][A_N_HU] = fma(h, rs.un, acc[c][A_N_HU]);
-                  acc[c][A_N_HD] = fma(h, rs.dn, acc[c][A_N_HD]);
-                }
-              } else {
-                const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
-                obs_term<GRAD>(as, x, y, p.b_s, p.d_s, p.isig_s, acc[c][A_S_R2], acc[c][A_S_H], acc[c][A_S_HX],
-                               acc[c][A_S_WS], h);
-                if (GRAD) {
-                  acc[c][A_S_HC] += rs.cum_iv ? h : 0.0;
-                  acc[c][A_S_HD] = fma(h, rs.ds, acc[c][A_S_HD]);
-                }
-              }
             }
           }
         }
@@ -429,6 +647,10 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_eval_kernel(const EvalArgs a) {
   }
 }
 
+// ================================================================================================
+// Small kernels
+// ================================================================================================
+
 // Fixed-order sum of the per-block partials: one block per chain.  out[chain][ABD_NOUT] may live in
 // mapped host memory (the 16 doubles per chain are the only thing that crosses PCIe per evaluation).
 __global__ __launch_bounds__(256) void abd_finalize_kernel(const double* __restrict__ partials, int n_blocks,
@@ -438,8 +660,17 @@ __global__ __launch_bounds__(256) void abd_finalize_kernel(const double* __restr
   const int k = threadIdx.x % ABD_NOUT;
   const int part = threadIdx.x / ABD_NOUT;  // 0..15
   const double* p = partials + (int64_t)chain * n_blocks * ABD_NOUT;
+  // fixed summation order for a given n_blocks; 8 independent loads in flight per thread
   double v = 0.0;
-  for (int b = part; b < n_blocks; b += 16) v += p[(int64_t)b * ABD_NOUT + k];
+  int b = part;
+  for (; b + 7 * 16 < n_blocks; b += 8 * 16) {
+    double q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = p[(int64_t)(b + u * 16) * ABD_NOUT + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += q[u];
+  }
+  for (; b < n_blocks; b += 16) v += p[(int64_t)b * ABD_NOUT + k];
   sm[part][k] = v;
   __syncthreads();
   if (threadIdx.x < ABD_NOUT) {
@@ -450,28 +681,23 @@ __global__ __launch_bounds__(256) void abd_finalize_kernel(const double* __restr
   }
 }
 
-// (G, N) gap-major int8 (PyMC's i_raw) -> (N, G) individual-major, 64x64 tiles through LDS.
-__global__ __launch_bounds__(256) void abd_transpose_i8_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst,
-                                                               int G, int N) {
-  __shared__ int8_t tile[64][65];
-  const int g0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int g = g0 + r, j = j0 + tx;
-    tile[r][tx] = (g < G && j < N) ? src[(int64_t)g * N + j] : 0;
-  }
-  __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int j = j0 + r, g = g0 + tx;
-    if (g < G && j < N) dst[(int64_t)j * G + g] = tile[tx][r];
-  }
+// (G, N) gap-major int8 (PyMC's i_raw, or vacs.T / pcrpos.T) -> packed words [nt][N]
+__global__ __launch_bounds__(256) void abd_pack_bits_kernel(const int8_t* __restrict__ src, uint64_t* __restrict__ dst,
+                                                            int G, int N, int nt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (j >= N || t >= nt) return;
+  uint64_t w = 0;
+  const int g_end = min(64, G - t * 64);
+  for (int b = 0; b < g_end; ++b) w |= (uint64_t)(src[(int64_t)(t * 64 + b) * N + j] != 0) << b;  // coalesced over j
+  dst[(int64_t)t * N + j] = w;
 }
 
-__global__ void abd_flip_kernel(int8_t* iraw_ng, int8_t* waner, int G, int N, int64_t flat) {
+__global__ void abd_flip_kernel(uint64_t* rw, int8_t* waner, int G, int N, int64_t flat) {
   const int64_t gn = (int64_t)G * N;
   if (flat < gn) {
     const int64_t g = flat / N, j = flat % N;
-    iraw_ng[j * G + g] ^= 1;
+    rw[(g >> 6) * N + j] ^= 1ull << (g & 63);
   } else {
     waner[flat - gn] ^= 1;
   }
@@ -481,39 +707,31 @@ __global__ void abd_flip_kernel(int8_t* iraw_ng, int8_t* waner, int G, int N, in
 __global__ __launch_bounds__(ABD_BLOCK) void abd_deterministics_kernel(const EvalArgs a, int8_t* __restrict__ out_i,
                                                                        double* __restrict__ out_mun,
                                                                        double* __restrict__ out_mus) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  double2_t* tabs = reinterpret_cast<double2_t*>(smem_raw);
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   const int G = a.G, N = a.N, nt = a.nt, tstride = G + 1;
   double2_t* tab_ones = tabs + 2 * tstride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const ChainPar& p = a.ch[0];
-  fill_pow_table(tabs, p.rho_n, G, tid, ABD_BLOCK);
-  fill_pow_table(tabs + tstride, p.rho_s, G, tid, ABD_BLOCK);
-  for (int e = tid; e <= G; e += ABD_BLOCK) {
-    double2_t v;
-    v.x = e == 0 ? 0.0 : 1.0;
-    v.y = 0.0;
-    tab_ones[e] = v;
-  }
+  fill_pow_table(tabs, p.rho_n, tstride, tid, ABD_BLOCK);
+  fill_pow_table(tabs + tstride, p.rho_s, tstride, tid, ABD_BLOCK);
+  fill_ones_table(tab_ones, tstride, tid, ABD_BLOCK);
   __syncthreads();
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
     uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
-    const int64_t row = (int64_t)j * G;
 #pragma unroll
     for (int t = 0; t < ABD_MAXT; ++t) {
       V[t] = P[t] = Rw[t] = 0;
       if (t < nt) {
-        const int g = t * 64 + lane;
-        const bool in = g < G;
-        V[t] = __ballot((in ? a.vacs[row + g] : 0) != 0);
-        P[t] = __ballot(((in && a.pcr) ? a.pcr[row + g] : 0) != 0);
-        Rw[t] = __ballot((in ? p.iraw[row + g] : 0) != 0);
+        V[t] = uniform_word(a.vw, (int64_t)t * N + j);
+        if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
+        Rw[t] = uniform_word(p.rw, (int64_t)t * N + j);
       }
     }
     constrain_masks(Rw, P, a, I);
-    const bool wj = p.waner[j] != 0;
+    const bool wj = __builtin_amdgcn_readfirstlane((int)p.waner[j]) != 0;
     const double2_t* ts = wj ? tabs + tstride : tab_ones;
     for (int t = 0; t < nt; ++t) {
       const int g = t * 64 + lane;

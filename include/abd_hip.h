@@ -128,8 +128,18 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
 int abd_kernel_timing(abd_ctx* ctx, int32_t enable);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
-/* Algorithmic bytes one launch of `n_chains` evaluations has to read:
- * dense: G*N*(4R + 2 + n_chains) + n_chains*N ; sparse: sum_A K_A*(2R + gap index) + ... */
+/* Tuning hook (benchmarks / experiments): number of 256-thread workgroups of the evaluation grid
+ * (<= 0 keeps the current value) and chains evaluated per wavefront (0 = automatic, else 1, 2 or 4). */
+int abd_set_launch_config(abd_ctx* ctx, int32_t blocks, int32_t chains_per_wave);
+
+/* Tuning hook for dense panels: gaps per (64 individuals, chain, segment) work item; 0 = automatic
+ * (enough items to fill the chip about 5 waves deep per SIMD), else 1..64. */
+int abd_set_segment_length(abd_ctx* ctx, int32_t seg_len);
+
+/* Compulsory bytes one launch of `n_chains` evaluations has to read in THIS library's device layout:
+ * dense: G*N*4R (the two [od, log_dilution] panels) + bit-packed indicator words
+ * (vacs, pcrpos, one i_raw per chain: 8 bytes per individual per 64 gaps each) + n_chains*N waner bytes.
+ * (SURVEY 8d's byte-per-cell figure, G*N*(4R + 2 + n_chains) + n_chains*N, is larger.) */
 int64_t abd_algorithmic_bytes(abd_ctx* ctx, int32_t n_chains);
 
 /* 1 if the observation panels were recognised as dense (one S and one N reading in every cell). */

@@ -129,8 +129,10 @@ def test_batched_chains(n_chains):
     ctx.enqueue(3, perm, np.array(thetas)[perm])
     ctx.wait()
     lp2, g2 = ctx.fetch(3, n_chains)
-    np.testing.assert_array_equal(lp2, lp[perm])
-    np.testing.assert_array_equal(g2, g[perm])
+    # a chain may land in a differently shaped launch group (4, 2 or 1 chains per workgroup) when the
+    # order changes, which changes the summation order: equal to rounding, not bitwise
+    np.testing.assert_allclose(lp2, lp[perm], rtol=1e-13)
+    np.testing.assert_allclose(g2, g[perm], rtol=1e-10, atol=1e-10 * np.abs(g).max())
 
 
 def test_bitwise_reproducible():

@@ -77,7 +77,6 @@ SYMBOLS = {
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
-    "abd_set_segment_length": (C.c_int, [_P, C.c_int32]),
     "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
     "abd_is_dense": (C.c_int, [_P]),
 }
@@ -307,9 +306,6 @@ class Context:
 
     def set_launch_config(self, blocks: int = 0, chains_per_wave: int = 0):
         _check(self._lib, self._lib.abd_set_launch_config(self._h, int(blocks), int(chains_per_wave)))
-
-    def set_segment_length(self, seg_len: int = 0):
-        _check(self._lib, self._lib.abd_set_segment_length(self._h, int(seg_len)))
 
     def kernel_time(self, reset: bool = True):
         ms = C.c_double()

@@ -42,7 +42,7 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int kResultSlots = 1024;
-constexpr int kMinSegLen = 4;
+constexpr int kMinRows = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
 struct AntigenDev {
@@ -81,7 +81,7 @@ struct abd_ctx {
   int blocks_x = 0;       // sparse kernel grid
   int blocks_max = 0;     // rows per chain in `partials`
   int cpw_forced = 0;
-  int seg_len_forced = 0;
+  int dense_blocks = 0;   // dense kernel grid.x
   uint64_t chunk_mask[3][ABD_MAXT] = {};
   AntigenDev s, n;
   uint64_t* vw = nullptr;  // [nt][N]
@@ -312,20 +312,13 @@ int pick_cpw(const abd_ctx* c, int n) {
   return 1;
 }
 
-// gaps per segment of the dense kernel for a launch of n chains: enough (lane group, chain, segment)
-// waves to fill the chip ~5 deep, segments no longer than a 64-bit word
-int pick_seg_len(const abd_ctx* c, int n) {
-  const int G = c->G;
-  int len;
-  if (c->seg_len_forced > 0) {
-    len = c->seg_len_forced;
-  } else {
-    const int64_t target_waves = (int64_t)c->n_cu * 4 * 5;
-    const int64_t per_seg = (int64_t)c->n_lg * n;
-    const int64_t n_seg = std::max<int64_t>(1, (target_waves + per_seg - 1) / per_seg);
-    len = (int)((G + n_seg - 1) / n_seg);
-  }
-  return std::max(kMinSegLen, std::min({len, 64, G}));
+// grid of the dense kernel: an exact multiple of the CU count (every wave slot gets the same number of
+// gap rows), capped so a slot has at least kMinRows rows
+int dense_blocks(const abd_ctx* c, int cpw) {
+  const int nsub = ABD_WAVES_PER_BLOCK / cpw;
+  const int64_t rows = (int64_t)c->n_lg * c->G;
+  const int64_t cap = std::max<int64_t>(1, rows / ((int64_t)kMinRows * nsub));
+  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)c->dense_blocks, cap, (int64_t)c->blocks_max}));
 }
 
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
@@ -338,10 +331,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   int blocks;
   size_t lds;
   if (c->dense) {
-    a.seg_len = pick_seg_len(c, n);
-    a.n_seg = (c->G + a.seg_len - 1) / a.seg_len;
-    const int nsub = ABD_WAVES_PER_BLOCK / cpw;
-    blocks = a.n_seg * ((c->n_lg + nsub - 1) / nsub);
+    blocks = dense_blocks(c, cpw);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
   } else {
     blocks = c->blocks_x;
@@ -607,11 +597,12 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_BLOCKS_PER_CU")) bpc = std::max(1, std::atoi(e));
   const int sparse_max = std::max(1, std::min((N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 16));
   c->blocks_x = std::max(1, std::min(sparse_max, c->n_cu * bpc));
-  // dense kernel: one block per (segment, lane group[s]); at most ceil(G / kMinSegLen) segments
-  const int dense_max = ((G + kMinSegLen - 1) / kMinSegLen) * c->n_lg;
-  c->blocks_max = c->dense ? std::max(dense_max, sparse_max) : sparse_max;
+  // dense kernel: 5 workgroups per CU (<= 96 VGPRs, ~29 KB LDS each)
+  int dbpc = 5;
+  if (const char* e = std::getenv("ABD_DENSE_BLOCKS_PER_CU")) dbpc = std::max(1, std::atoi(e));
+  c->blocks_max = std::max(sparse_max, c->n_cu * 16);
+  c->dense_blocks = std::min(c->n_cu * dbpc, c->blocks_max);
   if (const char* e = std::getenv("ABD_CPW")) c->cpw_forced = std::atoi(e);
-  if (const char* e = std::getenv("ABD_SEG_LEN")) c->seg_len_forced = std::atoi(e);
   if (table_lds_bytes(G, 4, 16) > 160 * 1024) {
     free_ctx(c);
     return fail(ABD_ERR_ARG, "LDS tables for n_gaps=%d do not fit", G);
@@ -780,14 +771,12 @@ int abd_set_launch_config(abd_ctx* c, int32_t blocks, int32_t chains_per_wave) {
   if (!(chains_per_wave == 0 || chains_per_wave == 1 || chains_per_wave == 2 || chains_per_wave == 4))
     return fail(ABD_ERR_ARG, "chains_per_wave must be 0 (auto), 1, 2 or 4");
   c->cpw_forced = chains_per_wave;
-  if (blocks > 0 && !c->dense) c->blocks_x = std::max(1, std::min(blocks, c->blocks_max));
-  return ABD_OK;
-}
-
-int abd_set_segment_length(abd_ctx* c, int32_t seg_len) {
-  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
-  if (seg_len < 0 || seg_len > 64) return fail(ABD_ERR_ARG, "segment length must be 0 (auto) or in [1, 64]");
-  c->seg_len_forced = seg_len;
+  if (blocks > 0) {
+    if (c->dense)
+      c->dense_blocks = std::max(1, std::min(blocks, c->blocks_max));
+    else
+      c->blocks_x = std::max(1, std::min(blocks, c->blocks_max));
+  }
   return ABD_OK;
 }
 

@@ -12,12 +12,11 @@
 //
 // Dense panels (benchmark configs; exactly one S and one N reading per cell): the OD panels are held
 // gap-major, (G, N) arrays of [od, log_dilution] pairs -- the reference's own (gap, ind) orientation.
-// A LANE owns one individual and walks a segment of consecutive gaps, so a wave's load of one gap row is
-// 64 contiguous pairs (1 KiB), there is no cross-lane traffic until the final reduction, and no lane is
-// idle whatever G is.  Work item = (64 individuals, chain, gap segment); the state a segment starts from
-// (titer responses, their rho-sensitivities, exposure flags) is rebuilt per lane from the packed words:
-// constrain on the words, then the reference's dense design summed over the set bits before the segment
-// with rho^k read from an LDS table.  The 4 waves of a workgroup are 4 chains of the same item, so the
+// A LANE owns one individual and walks consecutive gaps, so a wave's load of one gap row is 64 contiguous
+// pairs (1 KiB), there is no cross-lane traffic until the final reduction, and no lane is idle whatever
+// G is.  The (64-individual group, gap) plane is cut into equal ranges, one per wave slot; the state a
+// range starts from (titer responses, their rho-sensitivities, exposure flags) is rebuilt per lane from
+// the packed words (abd_dense.hpp).  The 4 waves of a workgroup are 4 chains of the same range, so the
 // panel rows they share are fetched from HBM once and served from L1/L2 to the others.
 //
 // Sparse observation lists (the real cohorts): one wave per individual, lanes over its observations
@@ -84,8 +83,7 @@ struct EvalArgs {
   const uint64_t* pw;  // nullptr = ignore_pcrpos
   double* partials;    // [n_chains][grid.x][ABD_NOUT]
   int32_t G, N, nt, n_chunks;
-  int32_t n_chains, seg_len;  // dense: gaps per segment (<= 64)
-  int32_t n_seg, n_lg;        // dense: segments per individual, 64-individual lane groups
+  int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
   uint64_t chunk_mask[3][ABD_MAXT];
   ChainPar ch[ABD_MAX_BATCH_K];
 };
@@ -98,6 +96,12 @@ template <typename R>
 struct YX {
   R y, x;
 };
+
+// force a (wave-uniform) value into vector registers
+__device__ __forceinline__ double to_vgpr(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -158,6 +162,48 @@ __device__ __forceinline__ void fill_pow_table(double2_t* tab, double rho, int n
         v.y = (double)k * acc;
       }
     }
+    tab[e] = v;
+  }
+}
+
+// Same table filled by ONE wave (dense kernel: each wave owns one chain).  Entry e >= 2 needs rho^(e-2):
+// lane l holds z_l = rho^((l + 62) mod 64) from one 6-step binary powering, and entry e = 64 b + l is
+// z_l times rho^(64 b) (lanes >= 2) or rho^(64 (b-1)) (lanes 0, 1) -- 3 multiplies per entry.
+__device__ __forceinline__ void fill_pow_table_wave(double2_t* tab, double rho, int n_entries, int lane) {
+  double base = rho, z = 1.0;
+  int n = (lane + 62) & 63;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    if (n & 1) z *= base;
+    base *= base;
+    n >>= 1;
+  }
+  // base = rho^64
+  double m_cur = 1.0, m_prev = 0.0;  // rho^(64 b), rho^(64 (b - 1))
+  for (int b0 = 0; b0 < n_entries; b0 += 64) {
+    const int e = b0 + lane;
+    double2_t v;
+    const double pkm1 = z * (lane < 2 ? m_prev : m_cur);  // rho^(e - 2)
+    v.x = pkm1 * rho;
+    v.y = (double)(e - 1) * pkm1;
+    if (e == 0) {
+      v.x = 0.0;  // index for "exposure is in the future"
+      v.y = 0.0;
+    } else if (e == 1) {
+      v.x = 1.0;  // rho^0 = 1 also for rho = 0 (abd.py:258: rho**design with design = 0)
+      v.y = 0.0;
+    }
+    if (e < n_entries) tab[e] = v;
+    m_prev = m_cur;
+    m_cur *= base;
+  }
+}
+
+__device__ __forceinline__ void fill_ones_table_wave(double2_t* tab, int n_entries, int lane) {
+  for (int e = lane; e < n_entries; e += 64) {
+    double2_t v;
+    v.x = e == 0 ? 0.0 : 1.0;
+    v.y = 0.0;
     tab[e] = v;
   }
 }
@@ -228,24 +274,23 @@ __device__ __forceinline__ double ld(const void* p, int64_t k) {
   return (double)reinterpret_cast<const R*>(p)[k];
 }
 
-// exp(x) for x <= 708 (callers clamp): Cody-Waite reduction by ln 2, degree-12 Taylor on
-// |f| <= ln2/2 (truncation 1.7e-16 relative), scale by 2^k.  17 VALU, no special-case branches.
+// exp(x) for x <= 708 (callers clamp): Cody-Waite reduction by ln 2, degree-10 near-minimax polynomial
+// on |f| <= ln2/2 (interpolation at Chebyshev nodes, tools/exp_poly.py: max relative error 3.3e-16),
+// scale by 2^k.  15 VALU, no special-case branches.
 __device__ __forceinline__ double exp_reduced(double x) {
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double f = fma(k, -6.93147180369123816490e-01, x);
   f = fma(k, -1.90821492927058770002e-10, f);
-  double p = 2.08767569878680989792e-09;            // 1/12!
-  p = fma(p, f, 2.50521083854417187751e-08);        // 1/11!
-  p = fma(p, f, 2.75573192239858906526e-07);        // 1/10!
-  p = fma(p, f, 2.75573192239858906526e-06);        // 1/9!
-  p = fma(p, f, 2.48015873015873015873e-05);        // 1/8!
-  p = fma(p, f, 1.98412698412698412698e-04);        // 1/7!
-  p = fma(p, f, 1.38888888888888888889e-03);        // 1/6!
-  p = fma(p, f, 8.33333333333333333333e-03);        // 1/5!
-  p = fma(p, f, 4.16666666666666666667e-02);        // 1/4!
-  p = fma(p, f, 1.66666666666666666667e-01);        // 1/3!
-  p = fma(p, f, 0.5);
-  p = fma(p, f, 1.0);
+  double p = 2.7626357241447223e-07;
+  p = fma(p, f, 2.764018079620985e-06);
+  p = fma(p, f, 2.4801504346997686e-05);
+  p = fma(p, f, 0.00019841170270440067);
+  p = fma(p, f, 0.0013888888932488599);
+  p = fma(p, f, 0.008333333385667782);
+  p = fma(p, f, 0.04166666666657314);
+  p = fma(p, f, 0.16666666666554406);
+  p = fma(p, f, 0.5000000000000006);
+  p = fma(p, f, 1.0000000000000067);
   p = fma(p, f, 1.0);
   return ldexp(p, (int)k);
 }
@@ -282,178 +327,7 @@ __device__ __forceinline__ void obs_term(double a, double x, double y, double b,
 // Dense-panel kernel: lane = individual, wave = (64 individuals, chain, gap segment)
 // ================================================================================================
 
-// bits [g0, g0 + len) of the packed row, moved to bit 0 (len <= 64; g0 wave-uniform).  Every word is
-// visited with a compile-time index (a runtime-indexed register array would go to scratch).
-__device__ __forceinline__ uint64_t extract_bits(const uint64_t w[ABD_MAXT], int g0, int len) {
-  uint64_t v = 0;
-#pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
-    const int sh = g0 - t * 64;  // wave-uniform
-    if (sh >= 0 && sh < 64) v |= w[t] >> sh;
-    if (sh < 0 && sh > -64) v |= w[t] << (-sh);
-  }
-  return len >= 64 ? v : (v & ((1ull << len) - 1ull));
-}
-
-template <typename R, int CB, bool GRAD>
-__global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) {
-  // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int G = a.G, N = a.N, nt = a.nt;
-  const int tstride = G + 1;
-  double2_t* tabs = reinterpret_cast<double2_t*>(smem);
-  double2_t* tab_ones = tabs + CB * 2 * tstride;
-  double* red = reinterpret_cast<double*>(tab_ones + tstride);  // [WAVES][ABD_NOUT]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NSUB = ABD_WAVES_PER_BLOCK / CB;  // lane groups per block
-  const int c = wave % CB;                        // this wave's chain within the block's group
-  const int sub = wave / CB;
-  const int cbase = blockIdx.y * CB;
-  const ChainPar& p = a.ch[cbase + c];
-
-  const int n_lgb = (a.n_lg + NSUB - 1) / NSUB;
-  const int seg = blockIdx.x / n_lgb;             // lane-group index fastest: neighbours in time are
-  const int lg = (blockIdx.x % n_lgb) * NSUB + sub;  // neighbours in every gap row
-  const int g0 = seg * a.seg_len;
-  const int len = min(a.seg_len, G - g0);
-  const bool wave_on = lg < a.n_lg;
-  const int j_raw = lg * 64 + lane;
-  const bool active = wave_on && j_raw < N;
-  const int j = active ? j_raw : N - 1;
-
-  // power tables up to the exponents a segment start can need (k < g0)
-  const int n_entries = g0 + 1;
-  if (g0 > 0) {
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) {
-      fill_pow_table(tabs + (cc * 2 + 0) * tstride, a.ch[cbase + cc].rho_n, n_entries, tid, ABD_BLOCK);
-      fill_pow_table(tabs + (cc * 2 + 1) * tstride, a.ch[cbase + cc].rho_s, n_entries, tid, ABD_BLOCK);
-    }
-    fill_ones_table(tab_ones, n_entries, tid, ABD_BLOCK);
-  }
-
-  // ---- packed indicator rows of this lane's individual; constrain (abd.py:640-667) ----
-  uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
-#pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
-    V[t] = P[t] = Rw[t] = 0;
-    if (t < nt) {
-      V[t] = a.vw[(int64_t)t * N + j];
-      if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
-      Rw[t] = p.rw[(int64_t)t * N + j];
-    }
-  }
-  const bool wj = p.waner[j] != 0;
-  constrain_masks(Rw, P, a, I);
-
-  double acc[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = 0.0;
-  if (seg == 0 && active) {
-    int n1 = 0;
-#pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) n1 += __builtin_popcountll(Rw[t]);  // Bernoulli(i_raw | p) is on the RAW matrix
-    acc[ABD_NACC] = (double)n1;
-    acc[ABD_NACC + 1] = wj ? 1.0 : 0.0;
-  }
-
-  // ---- state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures ----
-  double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
-  bool cum_i = false, cum_iv = false;
-  __syncthreads();
-  if (g0 > 0) {
-    const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
-    const double2_t* tab_s = wj ? tabs + (c * 2 + 1) * tstride : tab_ones;
-#pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
-      if (t * 64 < g0) {
-        const int rel = g0 - t * 64;  // bits < rel of word t are before the segment
-        const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
-        uint64_t mi = I[t] & below, mv = V[t] & below;
-        cum_i |= mi != 0;
-        cum_iv |= (mi | mv) != 0;
-        while (mi) {  // per-lane trip count
-          const int b = __builtin_ctzll(mi);
-          mi &= mi - 1;
-          const int idx = g0 - (t * 64 + b);  // = k + 1 with k = (g0 - 1) - r
-          const double2_t pn = tab_n[idx];
-          const double2_t ps = tab_s[idx];
-          tn += pn.x;
-          dn += pn.y;
-          ts += ps.x;
-          ds += ps.y;
-        }
-        while (mv) {
-          const int b = __builtin_ctzll(mv);
-          mv &= mv - 1;
-          const double2_t ps = tab_s[g0 - (t * 64 + b)];
-          ts += ps.x;
-          ds += ps.y;
-        }
-      }
-    }
-  }
-
-  // ---- walk the segment: recurrence form (abd.py:288) + likelihood terms ----
-  const uint64_t seg_i = extract_bits(I, g0, len);
-  const uint64_t seg_v = extract_bits(V, g0, len);
-  const double rho_n = p.rho_n, temp_n = p.temp_n;
-  const double rho_j = wj ? p.rho_s : 1.0;                        // abd.py:374
-  const double base_n0 = p.init_n, base_n1 = p.init_n + p.perm_n; // perm after the first infection   abd.py:306, 330
-  const double base_s0 = p.init_s, base_s1 = p.init_s + p.perm_s; // ... first infection or vaccination abd.py:368
-  const double b_n = p.b_n, d_n = p.d_n, b_s = p.b_s, d_s = p.d_s;
-  const double guard = active ? 1.0 : 0.0;
-  const YX<R>* yxn = reinterpret_cast<const YX<R>*>(a.yx_n) + (int64_t)g0 * N + j;
-  const YX<R>* yxs = reinterpret_cast<const YX<R>*>(a.yx_s) + (int64_t)g0 * N + j;
-  double hd_s = 0.0;
-
-  if (wave_on) {
-#pragma unroll 2
-    for (int gi = 0; gi < len; ++gi) {
-      const YX<R> on = yxn[(int64_t)gi * N];
-      const YX<R> os = yxs[(int64_t)gi * N];
-      const bool ib = (seg_i >> gi) & 1ull;
-      const bool vb = (seg_v >> gi) & 1ull;
-      dn = fma(rho_n, dn, tn);
-      tn = fma(rho_n, tn, ib ? 1.0 : 0.0);
-      ds = fma(rho_j, ds, ts);
-      ts = fma(rho_j, ts, (ib ? 1.0 : 0.0) + (vb ? 1.0 : 0.0));  // unit boosts: temp unused (abd.py:272)
-      cum_i |= ib;
-      cum_iv |= ib | vb;
-      // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
-      const double an = fma(temp_n, tn, cum_i ? base_n1 : base_n0);
-      const double as = (cum_iv ? base_s1 : base_s0) + ts;
-      double h = 0.0;
-      obs_term<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, guard, acc[A_N_Q2], acc[A_N_H], acc[A_N_HX], acc[A_N_QS], h);
-      if (GRAD) {
-        acc[A_N_HC] += cum_i ? h : 0.0;
-        acc[A_N_HU] = fma(h, tn, acc[A_N_HU]);
-        acc[A_N_HD] = fma(h, dn, acc[A_N_HD]);
-      }
-      obs_term<GRAD>(as, (double)os.x, (double)os.y, b_s, d_s, guard, acc[A_S_Q2], acc[A_S_H], acc[A_S_HX], acc[A_S_QS], h);
-      if (GRAD) {
-        acc[A_S_HC] += cum_iv ? h : 0.0;
-        hd_s = fma(h, ds, hd_s);
-      }
-    }
-  }
-  acc[A_S_HD] = wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
-
-  // ---- reduction: lanes -> wave -> block (LDS) -> per-block partial in global memory ----
-  const double tot = wave_reduce16(acc, lane);
-  if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
-  __syncthreads();
-  if (tid < CB * ABD_NOUT) {
-    const int cc = tid / ABD_NOUT, k = tid % ABD_NOUT;
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
-    a.partials[((int64_t)(cbase + cc) * gridDim.x + blockIdx.x) * ABD_NOUT + k] = v;
-  }
-}
+#include "abd_dense.hpp"
 
 // ================================================================================================
 // Sparse-list kernel (the real cohorts: several dilutions per serum sample, most cells empty)

@@ -132,9 +132,6 @@ int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t r
  * (<= 0 keeps the current value) and chains evaluated per wavefront (0 = automatic, else 1, 2 or 4). */
 int abd_set_launch_config(abd_ctx* ctx, int32_t blocks, int32_t chains_per_wave);
 
-/* Tuning hook for dense panels: gaps per (64 individuals, chain, segment) work item; 0 = automatic
- * (enough items to fill the chip about 5 waves deep per SIMD), else 1..64. */
-int abd_set_segment_length(abd_ctx* ctx, int32_t seg_len);
 
 /* Compulsory bytes one launch of `n_chains` evaluations has to read in THIS library's device layout:
  * dense: G*N*4R (the two [od, log_dilution] panels) + bit-packed indicator words

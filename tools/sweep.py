@@ -32,8 +32,6 @@ print(f"# {ctx.device_name}  N={N} G={G} chains={C} storage={args.storage} alg_b
 for cpw in [int(x) for x in args.cpw.split(",")]:
     for blocks in [int(x) for x in args.blocks.split(",")]:
         ctx.set_launch_config(blocks, cpw)
-        if ctx.is_dense:
-            ctx.set_segment_length(blocks)
         for k in range(5):
             ctx.enqueue(k, chains, th[k])
         ctx.wait()

@@ -68,6 +68,7 @@ SYMBOLS = {
     "abd_flip_discrete": (C.c_int, [_P, C.c_int32, C.c_int64]),
     "abd_logp": (C.c_int, [_P, C.c_int32, _D, _D]),
     "abd_logp_dlogp": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "abd_loglik_dlogp": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
     "abd_logp_dlogp_batch": (C.c_int, [_P, C.c_int32, _I32, _D, _D, _D]),
     "abd_n_result_slots": (C.c_int, [_P]),
     "abd_logp_dlogp_batch_enqueue": (C.c_int, [_P, C.c_int32, C.c_int32, _I32, _D]),
@@ -250,6 +251,16 @@ class Context:
         out = C.c_double()
         g = np.empty(N_THETA)
         _check(self._lib, self._lib.abd_logp_dlogp(self._h, chain, _ptr(t, C.c_double), C.byref(out), _ptr(g, C.c_double)))
+        return out.value, g
+
+    def loglik_dlogp(self, chain: int, theta):
+        """Data term only (the two observed Normals) and its gradient w.r.t. theta."""
+        t = _as(theta, np.float64)
+        if t.shape != (N_THETA,):
+            raise ValueError(f"theta must have shape ({N_THETA},)")
+        out = C.c_double()
+        g = np.empty(N_THETA)
+        _check(self._lib, self._lib.abd_loglik_dlogp(self._h, chain, _ptr(t, C.c_double), C.byref(out), _ptr(g, C.c_double)))
         return out.value, g
 
     def logp_dlogp_batch(self, chains, theta):

@@ -1,0 +1,85 @@
+"""
+``abdpymc-infer``: same flags and flow as the reference entry point (abd.py:885-924) --
+TiterData.from_disk -> calculate_splits -> model(...) -> sample(tune, draws) -> write the posterior.
+
+With PyMC installed the model can instead be handed to ``pm.sample`` through
+:mod:`abdpymc_amd.pytensor_op`; this command uses the built-in compound sampler (NUTS + binary Gibbs) so it
+runs on a box that has neither PyMC nor ArviZ.  Output: ArviZ NetCDF when ArviZ is importable, else a
+``.npz`` with the same variable names (leading axes chain, draw; Deterministics with trailing gap, ind).
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser("abdpymc-infer")
+    # reference flags, verbatim (abd.py:888-911)
+    parser.add_argument("--tune", help="Number of tuning steps.", type=int, required=True)
+    parser.add_argument("--draws", help="Number of draws.", type=int, required=True)
+    parser.add_argument("--cores", help="Number of cores", type=int)
+    parser.add_argument("--ititers_data", help="Path to directory for generating TiterData object.", default="cohort_data")
+    parser.add_argument("--split_delta", help="Split time chunk between delta and pre-delta", action="store_true")
+    parser.add_argument("--split_omicron", help="Split time chunk between omicron and delta", action="store_true")
+    parser.add_argument("--ignore_pcrpos", help="Ignore PCR+ data", action="store_true")
+    parser.add_argument("--netcdf", help="Path of netCDF file to save.")
+    # additions (all optional)
+    parser.add_argument("--chains", help="Number of chains (default: --cores or 1).", type=int)
+    parser.add_argument("--seed", help="Random seed.", type=int, default=0)
+    parser.add_argument("--device", help="HIP device ordinal.", type=int, default=-1)
+    parser.add_argument("--no_deterministics", help="Do not record i / ab_n_mu / ab_s_mu per draw.", action="store_true")
+    return parser
+
+
+def write_posterior(res: dict, path: str, coords: dict) -> str:
+    try:
+        import arviz as az  # noqa: F401
+    except ImportError:
+        az = None
+    if az is not None and path:
+        dims = {"i_raw": ["gap", "ind"], "i": ["gap", "ind"], "ab_n_mu": ["gap", "ind"], "ab_s_mu": ["gap", "ind"],
+                "ab_s_waner": ["ind"]}
+        post = {k: v for k, v in res.items() if not k.startswith("stat_") and k != "n_grad_evals"}
+        stats = {k[5:]: v for k, v in res.items() if k.startswith("stat_")}
+        idata = az.from_dict(posterior=post, sample_stats=stats, coords=coords, dims=dims)
+        az.to_netcdf(idata, path)  # abd.py:924
+        return path
+    out = (path or "abd_posterior") + ("" if str(path or "").endswith(".npz") else ".npz")
+    np.savez_compressed(out, **res, coord_gap=coords["gap"], coord_ind=coords["ind"])
+    return out
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    from .data import TiterData
+    from .model import model
+    from .sampler import sample
+
+    data = TiterData.from_disk(args.ititers_data)  # abd.py:913
+    splits = (
+        None
+        if (not args.split_delta) and (not args.split_omicron)
+        else data.calculate_splits(delta=args.split_delta, omicron=args.split_omicron)
+    )  # abd.py:915-919
+    chains = args.chains or args.cores or 1
+    m = model(data, splits=splits, ignore_pcrpos=args.ignore_pcrpos, n_chains=chains, device=args.device)  # abd.py:921
+    t0 = time.time()
+
+    def progress(c, a, b):
+        if a == b or a % max(1, b // 10) == 0:
+            print(f"chain {c}: {a}/{b} iterations, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+
+    res = sample(m, tune=args.tune, draws=args.draws, chains=chains, seed=args.seed,
+                 record_deterministics=not args.no_deterministics, progress=progress)  # abd.py:922
+    out = write_posterior(res, args.netcdf, data.coords)
+    print(f"wrote {out}  ({chains} chains x {args.draws} draws on {m.ctx.device_name})", file=sys.stderr)
+    m.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -193,11 +193,15 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
 // Combine the device sums of one chain with the host-side terms.  The device accumulates
 //   Q2 = sum q^2, H.. = sums of h' = q s (1 - s), QS = sum q s   with q = od - d s   (abd_kernels.hpp)
 // so  ll = -1/2 Q2 / sigma^2 - K (log sigma + 1/2 log 2 pi),  d ll / d a_k = -b (d / sigma^2) h'_k.
-void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad) {
+void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad, bool with_priors = true) {
   const Transformed tr = transform(t);
   const double n1 = sums[ABD_NACC], m1 = sums[ABD_NACC + 1];
   const double cells = (double)c->G * (double)c->N;
-  double lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad);
+  double lp = 0.0;
+  if (with_priors)
+    lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad);
+  else if (grad)
+    std::fill(grad, grad + ABD_N_THETA, 0.0);
   const double Kn = (double)c->n.K, Ks = (double)c->s.K;
   const double is2_n = 1.0 / (tr.sig_n * tr.sig_n), is2_s = 1.0 / (tr.sig_s * tr.sig_s);
   lp += -0.5 * is2_n * sums[A_N_Q2] - Kn * (t[13] + 0.5 * kLog2Pi);
@@ -395,14 +399,14 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   return ABD_OK;
 }
 
-int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad) {
+int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true) {
   if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   const ResultSlot& r = c->results[slot];
   if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
   const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
   for (int k = 0; k < r.n; ++k)
     assemble(c, r.theta.data() + (size_t)k * ABD_N_THETA, rows + (size_t)k * ABD_NOUT, logp + k,
-             (grad && r.grad) ? grad + (size_t)k * ABD_N_THETA : nullptr);
+             (grad && r.grad) ? grad + (size_t)k * ABD_N_THETA : nullptr, with_priors);
   return ABD_OK;
 }
 
@@ -723,6 +727,14 @@ int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const dou
 
 int abd_logp_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* logp, double* grad) {
   return abd_logp_dlogp_batch(c, 1, &chain, theta, logp, grad);
+}
+
+int abd_loglik_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* loglik, double* grad) {
+  if (!c || !theta || !loglik || !grad) return fail(ABD_ERR_ARG, "NULL argument");
+  int rc = enqueue_slot(c, 0, 1, &chain, theta, true);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return fetch_slot(c, 0, loglik, grad, false);
 }
 
 int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {

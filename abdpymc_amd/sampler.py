@@ -1,0 +1,280 @@
+"""
+A self-contained compound sampler for the model's two callables, used by ``abdpymc-infer`` when PyMC is not
+installed: NUTS on the 17 continuous variables (calls ``logp_dlogp``) + binary Gibbs-Metropolis on
+``[i_raw, ab_s_waner]`` (calls ``logp`` once per proposed flip) -- the step assignment ``pm.sample`` makes for
+this model (reference call site abd.py:922).
+
+The samplers only see callables, so they are tested on CPU against closed-form targets; on the GPU they are
+driven by :class:`abdpymc_amd.model.AbdModel`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------------
+# NUTS (Hoffman & Gelman 2014, Algorithm 6: slice variant with dual-averaging step size), diagonal metric
+# ---------------------------------------------------------------------------------------------------
+
+
+class DualAveraging:
+    def __init__(self, eps0: float, target: float = 0.8, gamma: float = 0.05, t0: float = 10.0, kappa: float = 0.75):
+        self.mu = math.log(10.0 * eps0)
+        self.target, self.gamma, self.t0, self.kappa = target, gamma, t0, kappa
+        self.h_bar, self.log_eps_bar, self.m = 0.0, 0.0, 0
+        self.eps = eps0
+
+    def update(self, accept_stat: float) -> float:
+        self.m += 1
+        m = self.m
+        self.h_bar = (1 - 1 / (m + self.t0)) * self.h_bar + (self.target - accept_stat) / (m + self.t0)
+        log_eps = self.mu - math.sqrt(m) / self.gamma * self.h_bar
+        eta = m ** (-self.kappa)
+        self.log_eps_bar = eta * log_eps + (1 - eta) * self.log_eps_bar
+        self.eps = math.exp(log_eps)
+        return self.eps
+
+    def final(self) -> float:
+        return math.exp(self.log_eps_bar)
+
+
+class Nuts:
+    """One NUTS transition kernel over q in R^d for ``fn(q) -> (logp, grad)``."""
+
+    def __init__(self, fn: Callable[[np.ndarray], Tuple[float, np.ndarray]], dim: int, rng: np.random.Generator,
+                 max_treedepth: int = 10, target_accept: float = 0.8):
+        self.fn, self.dim, self.rng = fn, dim, rng
+        self.max_treedepth = max_treedepth
+        self.inv_mass = np.ones(dim)  # diagonal M^-1 (posterior variances)
+        self.da: Optional[DualAveraging] = None
+        self.eps = 0.1
+        self.target_accept = target_accept
+        self.n_grad = 0
+
+    def _grad(self, q):
+        self.n_grad += 1
+        lp, g = self.fn(q)
+        if not np.isfinite(lp):
+            return -np.inf, np.zeros_like(q)
+        return float(lp), np.asarray(g, dtype=float)
+
+    def _leapfrog(self, q, p, g, eps):
+        p = p + 0.5 * eps * g
+        q = q + eps * self.inv_mass * p
+        lp, g = self._grad(q)
+        p = p + 0.5 * eps * g
+        return q, p, lp, g
+
+    def _energy(self, lp, p):
+        return lp - 0.5 * float(np.sum(self.inv_mass * p * p))
+
+    def find_reasonable_eps(self, q, lp, g) -> float:
+        eps = 0.1
+        p = self.rng.standard_normal(self.dim) / np.sqrt(self.inv_mass)
+        h0 = self._energy(lp, p)
+        _, p1, lp1, _ = self._leapfrog(q, p, g, eps)
+        dh = self._energy(lp1, p1) - h0
+        a = 1.0 if (np.isfinite(dh) and dh > math.log(0.5)) else -1.0
+        for _ in range(50):
+            if not np.isfinite(dh):
+                dh = -np.inf
+            if a * dh <= -a * math.log(2.0):
+                break
+            eps *= 2.0**a
+            _, p1, lp1, _ = self._leapfrog(q, p, g, eps)
+            dh = self._energy(lp1, p1) - h0
+        return eps
+
+    def _build(self, q, p, g, log_u, v, j, eps, h0):
+        if j == 0:
+            q1, p1, lp1, g1 = self._leapfrog(q, p, g, v * eps)
+            h1 = self._energy(lp1, p1)
+            if not np.isfinite(h1):
+                h1 = -np.inf
+            n1 = int(log_u <= h1)
+            s1 = log_u < h1 + 1000.0
+            alpha = min(1.0, math.exp(min(0.0, h1 - h0))) if np.isfinite(h1) else 0.0
+            return q1, p1, g1, q1, p1, g1, q1, lp1, g1, n1, s1, alpha, 1
+        qm, pm, gm, qp, pp, gp, q1, lp1, g1, n1, s1, a1, na1 = self._build(q, p, g, log_u, v, j - 1, eps, h0)
+        if s1:
+            if v == -1:
+                qm, pm, gm, _, _, _, q2, lp2, g2, n2, s2, a2, na2 = self._build(qm, pm, gm, log_u, v, j - 1, eps, h0)
+            else:
+                _, _, _, qp, pp, gp, q2, lp2, g2, n2, s2, a2, na2 = self._build(qp, pp, gp, log_u, v, j - 1, eps, h0)
+            if n2 > 0 and self.rng.random() < n2 / max(n1 + n2, 1):
+                q1, lp1, g1 = q2, lp2, g2
+            a1, na1 = a1 + a2, na1 + na2
+            dq = qp - qm
+            s1 = s2 and float(np.dot(dq, self.inv_mass * pm)) >= 0 and float(np.dot(dq, self.inv_mass * pp)) >= 0
+            n1 += n2
+        return qm, pm, gm, qp, pp, gp, q1, lp1, g1, n1, s1, a1, na1
+
+    def step(self, q, lp, g, adapt: bool):
+        """One transition.  Returns (q, logp, grad, stats)."""
+        eps = self.eps
+        p0 = self.rng.standard_normal(self.dim) / np.sqrt(self.inv_mass)
+        h0 = self._energy(lp, p0)
+        log_u = h0 + math.log(self.rng.random() + 1e-300)
+        qm = qp = q
+        pm = pp = p0
+        gm = gp = g
+        j, n, s = 0, 1, True
+        q_new, lp_new, g_new = q, lp, g
+        alpha, n_alpha = 0.0, 1
+        while s and j < self.max_treedepth:
+            v = -1 if self.rng.random() < 0.5 else 1
+            if v == -1:
+                qm, pm, gm, _, _, _, q1, lp1, g1, n1, s1, alpha, n_alpha = self._build(qm, pm, gm, log_u, v, j, eps, h0)
+            else:
+                _, _, _, qp, pp, gp, q1, lp1, g1, n1, s1, alpha, n_alpha = self._build(qp, pp, gp, log_u, v, j, eps, h0)
+            if s1 and self.rng.random() < min(1.0, n1 / n):
+                q_new, lp_new, g_new = q1, lp1, g1
+            n += n1
+            dq = qp - qm
+            s = s1 and float(np.dot(dq, self.inv_mass * pm)) >= 0 and float(np.dot(dq, self.inv_mass * pp)) >= 0
+            j += 1
+        acc = alpha / max(n_alpha, 1)
+        if adapt and self.da is not None:
+            self.eps = self.da.update(acc)
+        return q_new, lp_new, g_new, dict(tree_depth=j, mean_tree_accept=acc, step_size=eps, n_steps=n_alpha,
+                                          diverging=not s and j < self.max_treedepth and acc == 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Binary Gibbs-Metropolis (PyMC's BinaryGibbsMetropolis.astep semantics: transit_p = 0.8, shuffled order)
+# ---------------------------------------------------------------------------------------------------
+
+
+def binary_gibbs_sweep(n_bits: int, flip_logp: Callable[[int], float], unflip: Callable[[int], None], logp_curr: float,
+                       rng: np.random.Generator, transit_p: float = 0.8):
+    """
+    One sweep over all binary dims in random order.  ``flip_logp(idx)`` flips bit idx of the resident state
+    and returns the joint logp there; ``unflip(idx)`` reverts a rejected flip.  Returns (logp, n_accepted,
+    n_proposed).
+    """
+    order = rng.permutation(n_bits)
+    propose = rng.random(n_bits) < transit_p
+    n_acc = n_prop = 0
+    for idx, do in zip(order, propose):
+        if not do:
+            continue  # same value proposed: nothing to evaluate
+        n_prop += 1
+        lp_prop = flip_logp(int(idx))
+        d = lp_prop - logp_curr
+        if np.isfinite(lp_prop) and (d >= 0 or math.log(rng.random() + 1e-300) < d):
+            logp_curr = lp_prop
+            n_acc += 1
+        else:
+            unflip(int(idx))
+    return logp_curr, n_acc, n_prop
+
+
+# ---------------------------------------------------------------------------------------------------
+# Compound driver for one chain of the abd model
+# ---------------------------------------------------------------------------------------------------
+
+
+def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_deterministics: bool = True,
+                 progress: Optional[Callable[[int, int], None]] = None) -> Dict[str, np.ndarray]:
+    """Run tune + draws iterations of [NUTS; binary Gibbs] on chain slot ``chain`` of an AbdModel."""
+    from .model import THETA_NAMES, constrain
+
+    rng = np.random.default_rng([seed, chain])
+    ctx = model.ctx
+    G, N = model.n_gaps, model.n_inds
+    pt = model.initial_point()
+    i_raw = pt["i_raw"].astype(np.int8)
+    waner = pt["ab_s_waner"].astype(np.int8)
+    ctx.set_discrete(chain, i_raw, waner)
+    q = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # jitter as pm.sample does
+
+    def fn(x):
+        return ctx.logp_dlogp(chain, x)
+
+    nuts = Nuts(fn, len(THETA_NAMES), rng)
+    lp, g = fn(q)
+    nuts.eps = nuts.find_reasonable_eps(q, lp, g)
+    nuts.da = DualAveraging(nuts.eps)
+
+    n_bits = G * N + N
+
+    def flip_logp(idx):
+        ctx.flip_discrete(chain, idx)
+        if idx < G * N:
+            i_raw.ravel()[idx] ^= 1
+        else:
+            waner[idx - G * N] ^= 1
+        return ctx.logp(chain, q)
+
+    def unflip(idx):
+        ctx.flip_discrete(chain, idx)
+        if idx < G * N:
+            i_raw.ravel()[idx] ^= 1
+        else:
+            waner[idx - G * N] ^= 1
+
+    out_q = np.empty((draws, len(THETA_NAMES)))
+    out_i_raw = np.empty((draws, G, N), dtype=np.int8)
+    out_w = np.empty((draws, N), dtype=np.int8)
+    stats = {k: np.empty(draws) for k in ("lp", "tree_depth", "mean_tree_accept", "step_size", "n_steps", "gibbs_accept")}
+    det = None
+    if record_deterministics:
+        det = dict(i=np.empty((draws, G, N), dtype=np.int8), ab_n_mu=np.empty((draws, G, N)), ab_s_mu=np.empty((draws, G, N)))
+
+    # mass-matrix adaptation: variances of the tuning draws in expanding windows
+    window_start, window_len = max(10, tune // 10), max(20, tune // 8)
+    window = []
+    for it in range(tune + draws):
+        tuning = it < tune
+        q, lp, g, st = nuts.step(q, lp, g, adapt=tuning)
+        lp, n_acc, n_prop = binary_gibbs_sweep(n_bits, flip_logp, unflip, lp, rng)
+        lp, g = fn(q)  # gradient at the new discrete state
+        if tuning:
+            if it >= window_start:
+                window.append(q.copy())
+            if len(window) >= window_len and it < tune - 20:
+                var = np.var(np.asarray(window), axis=0)
+                nuts.inv_mass = (len(window) / (len(window) + 5.0)) * var + 1e-3 * (5.0 / (len(window) + 5.0))
+                window, window_len = [], int(window_len * 1.5)
+                nuts.eps = nuts.find_reasonable_eps(q, lp, g)
+                nuts.da = DualAveraging(nuts.eps)
+            if it == tune - 1:
+                nuts.eps = nuts.da.final()
+        else:
+            k = it - tune
+            out_q[k] = q
+            out_i_raw[k] = i_raw
+            out_w[k] = waner
+            stats["lp"][k] = lp
+            for name in ("tree_depth", "mean_tree_accept", "step_size", "n_steps"):
+                stats[name][k] = st[name]
+            stats["gibbs_accept"][k] = n_acc / max(n_prop, 1)
+            if det is not None:
+                d_i, d_n, d_s = ctx.deterministics(chain, q)
+                det["i"][k], det["ab_n_mu"][k], det["ab_s_mu"][k] = d_i, d_n, d_s
+        if progress is not None:
+            progress(it + 1, tune + draws)
+
+    res = {name: out_q[:, k].copy() for k, name in enumerate(THETA_NAMES)}
+    res.update(constrain(out_q))
+    res["i_raw"] = out_i_raw
+    res["ab_s_waner"] = out_w
+    if det is not None:
+        res.update(det)
+    res.update({f"stat_{k}": v for k, v in stats.items()})
+    res["n_grad_evals"] = np.asarray(nuts.n_grad)
+    return res
+
+
+def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
+           progress: Optional[Callable[[int, int, int], None]] = None) -> Dict[str, np.ndarray]:
+    """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
+    if chains > model.n_chains:
+        raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
+    per_chain = []
+    for c in range(chains):
+        cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None
+        per_chain.append(sample_chain(model, c, tune, draws, seed, record_deterministics, cb))
+    return {k: np.stack([pc[k] for pc in per_chain]) for k in per_chain[0]}

@@ -195,7 +195,7 @@ def main():
             co.logp_dlogp(thetas[W + (n_done % K), 0], i_raw, w, nthreads=cores)
             n_done += 1
             el = time.perf_counter() - t2
-            if el >= args.cpu_seconds or n_done >= 2000:
+            if el >= args.cpu_seconds or n_done >= 20000:
                 break
         cpu = dict(value=round(n_done / el, 3), unit="evals/s", cores=cores, kind="port",
                    sample=f"{n_done} logp+grad evals of chain 0 at fresh thetas on the same cohort ({el:.1f} s), "

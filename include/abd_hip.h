@@ -103,6 +103,11 @@ int abd_logp(abd_ctx* ctx, int32_t chain, const double* theta, double* logp);
 /* logp and d logp / d theta.  Replaces Model.logp_dlogp_function() (a18). */
 int abd_logp_dlogp(abd_ctx* ctx, int32_t chain, const double* theta, double* logp, double* grad);
 
+/* Only the part of the joint logp that reads the OD panels -- the two observed Normal terms "it_n_lik",
+ * "it_s_lik" (abd.py:459-469) -- and its gradient w.r.t. theta (entries the data term does not depend on
+ * are 0).  For callers that keep the priors in PyMC and attach this as a pm.Potential. */
+int abd_loglik_dlogp(abd_ctx* ctx, int32_t chain, const double* theta, double* loglik, double* grad);
+
 /* n evaluations in as few launches as possible: chains[k] in [0, n_chain_slots), theta is n x 17,
  * logp n, grad n x 17.  The shared OD panels are read once per launch for all chains in it. */
 int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta,

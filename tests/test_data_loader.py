@@ -1,0 +1,110 @@
+"""
+The loader mirror (abdpymc_amd.data) against what the REFERENCE's TiterData.from_disk returned for the same
+files (tests/golden/loader_expect.json, made by tests/golden/make_fixtures.py), and against the facts the
+reference's own tests assert (test_abd.py:641-674: 10 individuals, 26 gaps, (10, 26) panels).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from abdpymc_amd.data import TiterData, check_splits
+from oracle import abd_oracle as O
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def expect(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "loader_expect.json")))
+
+
+def default_cohort(golden_dir) -> TiterData:
+    z = np.load(os.path.join(golden_dir, "default_cohort.npz"))
+    s = z["is_s"]
+    cols = lambda m: (z["elapsed_months"][m], z["individual_i"][m], z["log_dilution"][m], z["od"][m])  # noqa: E731
+    n_gaps = int(z["elapsed_months"].max()) + 1
+    n_inds = int(z["individual_i"].max()) + 1
+    return TiterData.from_arrays(n_gaps, n_inds, cols(s), cols(~s), z["vacs"], z["pcrpos"], t0=str(z["t0"]))
+
+
+def _check(td: TiterData, e: dict):
+    assert td.n_gaps == e["n_gaps"] and td.n_inds == e["n_inds"]
+    assert str(td.t0) == e["t0"]
+    assert list(td.vacs.shape) == e["vacs_shape"] and td.vacs.shape == td.pcrpos.shape
+    assert float(td.vacs.sum()) == e["vacs_sum"] and float(td.pcrpos.sum()) == e["pcrpos_sum"]
+    assert [int(td.coords["ind"][0]), int(td.coords["ind"][-1])] == e["coords_ind"]
+    assert [int(td.coords["gap"][0]), int(td.coords["gap"][-1])] == e["coords_gap"]
+    for a in (False, True):
+        for b in (False, True):
+            assert list(td.calculate_splits(delta=a, omicron=b)) == e["splits"][f"{int(a)}{int(b)}"]
+    for ag in ("s", "n"):
+        d, x = getattr(td, ag), e[ag]
+        assert len(d) == x["n_obs"] and d.n_gaps == x["n_gaps"] and d.n_inds == x["n_inds"]
+        assert sha(d.idx_gap.astype(np.int64)) == x["idx_gap_sha"]
+        assert sha(d.idx_ind.astype(np.int64)) == x["idx_ind_sha"]
+        assert sha(d.log_dilution) == x["log_dilution_sha"]
+        assert sha(d.od) == x["od_sha"]
+
+
+def test_test_cohort_matches_reference_loader(golden_dir, expect):
+    td = TiterData.from_disk(os.path.join(golden_dir, "test_cohort"))
+    _check(td, expect["test_cohort"])
+    # reference test_abd.py:641-674
+    assert td.n_inds == 10 and td.n_gaps == 26
+    assert td.vacs.shape == (10, 26) and td.pcrpos.shape == (10, 26)
+    assert list(td.coords["ind"]) == list(range(10)) and list(td.coords["gap"]) == list(range(26))
+
+
+def test_default_cohort_matches_reference_loader(golden_dir, expect):
+    td = default_cohort(golden_dir)
+    _check(td, expect["default_cohort"])
+    assert (td.n_inds, td.n_gaps) == (1520, 31)
+    assert td.calculate_splits(True, True) == (14, 20)
+
+
+def test_shape_mismatch_raises(golden_dir):
+    td = TiterData.from_disk(os.path.join(golden_dir, "test_cohort"))
+    with pytest.raises(ValueError, match="vacs and pcrpos are different shapes"):
+        TiterData(td.t0, td.s, td.n, td.vacs, td.pcrpos[:, :-1], td.n_gaps, td.n_inds)
+
+
+def test_check_splits_mirror(golden_dir):
+    td = TiterData.from_disk(os.path.join(golden_dir, "test_cohort"))
+    with pytest.raises(ValueError, match="split indexes must be positive"):
+        check_splits((-1,), td)
+    with pytest.raises(ValueError, match="ascending"):
+        check_splits((5, 2), td)
+    with pytest.raises(ValueError, match="largest split must be less than n_gaps - 1"):
+        check_splits((27,), td)
+    with pytest.raises(ValueError, match="not unique"):
+        check_splits((3, 3), td)
+    with pytest.raises(ValueError, match="must be ints"):
+        check_splits((3.0,), td)
+    check_splits((26,), td)
+    check_splits(None, td)
+    check_splits((), td)
+
+
+def test_logistic_matches_reference(expect):
+    e = expect["logistic"]
+    got = [float(O.logistic(x, a=e["a"], b=e["b"], d=e["d"])) for x in e["x"]]
+    assert got == e["y"]
+
+
+def test_recurrence_matches_reference_simulation(expect):
+    """simulation.py's per-individual loop (the reference's only pure-NumPy recurrence) == the oracle's scan form."""
+    e = expect["simulation_recurrence"]
+    inf = np.array(e["infections"])[:, None]
+    vac = np.array(e["vacs"], dtype=float)[:, None]
+    np.testing.assert_array_equal(inf[:, 0], np.array(e["pcrpos"], dtype=float))  # lam0 = 0: infections = PCR+
+    tn = O.temp_response_scan(inf, e["temp_i"], e["wane"])[:, 0]
+    ts = O.temp_response_scan(inf, e["temp_i"], e["wane"])[:, 0] + O.temp_response_scan(vac, e["temp_v"], e["wane"])[:, 0]
+    n = e["init"] + O.perm_response(inf, e["perm"])[:, 0] + tn
+    s = e["init"] + O.perm_response(inf + vac, e["perm"])[:, 0] + ts
+    np.testing.assert_allclose(n, e["n"], rtol=1e-13)
+    np.testing.assert_allclose(s, e["s"], rtol=1e-13)

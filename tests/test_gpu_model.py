@@ -1,0 +1,151 @@
+"""
+The host mirror on the GPU: abdpymc_amd.model(...) -> compile_logp / logp_dlogp_function / deterministics
+against the committed golden vectors and the live oracle, on the reference's own test cohort and default
+cohort (BASELINE config 1: sparse observation lists, several dilutions per sample), plus the sampler / CLI.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from abdpymc_amd.data import TiterData
+from oracle import abd_oracle as O
+from tests.test_data_loader import default_cohort
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _oracle_cohort(td):
+    return O.Cohort(td.n_gaps, td.n_inds, np.asarray(td.vacs, dtype=np.int8), np.asarray(td.pcrpos, dtype=np.int8),
+                    O.AntigenObs(*td.s.obs), O.AntigenObs(*td.n.obs))
+
+
+def _close(lp, g, lp_ref, g_ref):
+    assert abs(lp - lp_ref) <= RTOL * abs(lp_ref), (lp, lp_ref)
+    scale = np.maximum(np.abs(g_ref), 1e-6 * np.abs(g_ref).max())
+    assert (np.abs(np.asarray(g) - g_ref) / scale).max() <= RTOL
+
+
+@pytest.fixture(scope="module")
+def test_td(golden_dir):
+    return TiterData.from_disk(os.path.join(golden_dir, "test_cohort"))
+
+
+def test_golden_vectors_test_cohort(golden_dir, test_td):
+    from abdpymc_amd.model import THETA_NAMES, model
+
+    cases = json.load(open(os.path.join(golden_dir, "logp_golden.json")))["cases"]
+    built = {}
+    for c in cases:
+        key = (tuple(c["splits"]), c["ignore_pcrpos"])
+        if key not in built:
+            built[key] = model(test_td, splits=tuple(c["splits"]) or None, ignore_pcrpos=c["ignore_pcrpos"])
+        m = built[key]
+        point = {n: np.asarray(v) for n, v in zip(THETA_NAMES, c["theta"])}
+        point["i_raw"] = np.array(c["i_raw"], dtype=np.int64)
+        point["ab_s_waner"] = np.array(c["waner"], dtype=np.int64)
+        fn = m.logp_dlogp_function()
+        fn.set_extra_values(point)
+        lp, g = fn(m.ravel(point))
+        _close(lp, g, c["logp"], np.array(c["grad"]))
+        assert abs(m.compile_logp()(point) - c["logp"]) <= RTOL * abs(c["logp"])
+        det = m.deterministics(point)
+        np.testing.assert_array_equal(det["i"], np.array(c["i"], dtype=np.int8))  # integer pre-pass: bit-exact
+        assert det["i"].dtype == np.int8 and det["i"].shape == (26, 10)
+        np.testing.assert_allclose(det["ab_n_mu"][-1], c["mu_n_last"], rtol=1e-12)
+        np.testing.assert_allclose(det["ab_s_mu"][-1], c["mu_s_last"], rtol=1e-12)
+        assert abs(det["ab_n_mu"].sum() - c["mu_n_sum"]) <= 1e-10 * abs(c["mu_n_sum"])
+        assert abs(det["ab_s_mu"].sum() - c["mu_s_sum"]) <= 1e-10 * abs(c["mu_s_sum"])
+
+
+@pytest.mark.parametrize("splits", [None, (14,), (14, 20)])
+def test_default_cohort_config1(golden_dir, splits):
+    """N=1520, G=31, K_s=19508, K_n=16201: the sparse CSR kernel against the oracle and the plain-C port."""
+    from abdpymc_amd.model import model
+    from oracle import c_oracle
+
+    td = default_cohort(golden_dir)
+    coh = _oracle_cohort(td)
+    m = model(td, splits=splits, n_chains=2)
+    assert not m.ctx.is_dense
+    rng = np.random.default_rng(7)
+    pt = m.initial_point()
+    q0 = m.ravel(pt)
+    co = c_oracle.COracle(coh, splits)
+    for chain in range(2):
+        i_raw = (rng.random((td.n_gaps, td.n_inds)) < 1.0 / td.n_gaps).astype(np.int8)
+        w = (rng.random(td.n_inds) < 0.5).astype(np.int8)
+        theta = q0 + 0.3 * rng.standard_normal(17)
+        m.ctx.set_discrete(chain, i_raw, w)
+        lp, g = m.ctx.logp_dlogp(chain, theta)
+        _close(lp, g, *O.logp_dlogp(theta, i_raw, w, coh, splits))
+        _close(lp, g, *co.logp_dlogp(theta, i_raw, w))
+    # the PyMC initial point (i_raw = 0, waner = 1) evaluates and is finite
+    fn = m.logp_dlogp_function()
+    fn.set_extra_values(pt)
+    lp0, g0 = fn(q0)
+    assert np.isfinite(lp0) and np.all(np.isfinite(g0))
+
+
+def test_loglik_only_is_joint_minus_priors(test_td):
+    from abdpymc_amd.model import model
+
+    m = model(test_td)
+    coh = _oracle_cohort(test_td)
+    rng = np.random.default_rng(3)
+    i_raw = (rng.random((26, 10)) < 0.1).astype(np.int8)
+    w = (rng.random(10) < 0.5).astype(np.int8)
+    theta = m.ravel(m.initial_point()) + 0.2 * rng.standard_normal(17)
+    m.ctx.set_discrete(0, i_raw, w)
+    ll, gl = m.ctx.loglik_dlogp(0, theta)
+    lp, g = m.ctx.logp_dlogp(0, theta)
+    lp0, g0 = O.prior_logp_grad(theta, 26, 260, int(i_raw.sum()), 10, int(w.sum()))
+    assert abs((lp - ll) - lp0) <= 1e-9 * abs(lp)
+    np.testing.assert_allclose(g - gl, g0, rtol=1e-9, atol=1e-9 * np.abs(g).max())
+    assert gl[0] == 0 and gl[7] == 0 and gl[8] == 0 and gl[9] == 0
+
+
+def test_gibbs_flip_path_matches_fresh_upload(test_td):
+    """compile_logp()'s one-bit-changed fast path (device-side flip) == a fresh set_discrete."""
+    from abdpymc_amd.model import model
+
+    m = model(test_td, splits=(14, 20), n_chains=2)
+    coh = _oracle_cohort(test_td)
+    logp_fn = m.compile_logp(chain=0)
+    pt = m.initial_point()
+    rng = np.random.default_rng(5)
+    for _ in range(25):
+        k = int(rng.integers(0, 270))
+        if k < 260:
+            pt["i_raw"].ravel()[k] ^= 1
+        else:
+            pt["ab_s_waner"][k - 260] ^= 1
+        got = logp_fn(pt)
+        ref = O.logp_dlogp(m.ravel(pt), pt["i_raw"], pt["ab_s_waner"], coh, (14, 20))[0]
+        assert abs(got - ref) <= RTOL * abs(ref)
+
+
+def test_sampler_smoke_and_cli(tmp_path, golden_dir, test_td):
+    from abdpymc_amd import cli
+    from abdpymc_amd.model import model
+    from abdpymc_amd.sampler import sample
+
+    m = model(test_td, n_chains=2)
+    res = sample(m, tune=15, draws=10, chains=2, seed=1)
+    assert res["p"].shape == (2, 10) and res["i"].shape == (2, 10, 26, 10) and res["ab_s_mu"].shape == (2, 10, 26, 10)
+    assert np.all(np.isfinite(res["stat_lp"])) and np.all((res["p"] > 0) & (res["p"] < 1))
+    # recorded Deterministic i is the constrained i_raw of the same draw
+    coh = _oracle_cohort(test_td)
+    i_ref = O.constrain_infections(res["i_raw"][1, -1], np.asarray(test_td.pcrpos).T)
+    np.testing.assert_array_equal(res["i"][1, -1], i_ref)
+    out = tmp_path / "post"
+    rc = cli.main(["--tune", "5", "--draws", "4", "--cores", "1", "--ititers_data", os.path.join(golden_dir, "test_cohort"),
+                   "--split_delta", "--netcdf", str(out)])
+    assert rc == 0
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1
+    if files[0].suffix == ".npz":
+        z = np.load(files[0])
+        assert z["ab_n_mu"].shape == (1, 4, 26, 10) and z["it_s_sigma"].shape == (1, 4)

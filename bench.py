@@ -65,7 +65,7 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("ABD_BENCH_FORCE_DIST"):
         # torch is plumbing only: rendezvous, barrier and the RCCL gather of the sample block
         import torch
         import torch.distributed as dist
@@ -123,12 +123,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_steps(W, W + K, lp_all, g_all)
-    gathered = None
     if dist is not None:
-        block = torch.from_numpy(np.concatenate([lp_all[..., None], g_all], axis=-1)).cuda()
-        out = [torch.empty_like(block) for _ in range(world)]
-        dist.all_gather(out, block)  # the trivial RCCL gather of samples over xGMI
-        gathered = out
+        # the trivial RCCL gather of samples over xGMI: (world, steps, chains, 18) on every rank
+        from abdpymc_amd.distributed import gather_samples
+
+        gathered = gather_samples(np.concatenate([lp_all[..., None], g_all], axis=-1), dist, device="cuda")
+        assert gathered.shape == (world, K, C, 18)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -169,7 +169,7 @@ def main():
             traffic = None
     roofline = dict(
         bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-        traffic=traffic, kernel="abd_eval_kernel", kernel_us=round(k_avg_s * 1e6, 3), launches=int(k_n),
+        traffic=traffic, kernel="abd_dense_kernel", kernel_us=round(k_avg_s * 1e6, 3), launches=int(k_n),
         algorithmic_bytes_per_launch=int(alg_bytes), survey_bytes_per_launch=int(survey_bytes), evals_per_launch=C,
         note="achieved uses the smaller, bit-packed byte count; the kernel is fp64-VALU bound (see DESIGN.md)",
     )

@@ -91,6 +91,8 @@ struct abd_ctx {
   double* partials = nullptr;  // [n_slots][blocks_max][ABD_NOUT]
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
+  double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
+  int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
   std::vector<ResultSlot> results;
   hipStream_t stream = nullptr;
   // timing
@@ -365,8 +367,21 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
                                      : launch_sparse<double>(cpw, grad, grid, lds, c->stream, a);
   if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(le);
-  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(256), 0, c->stream, c->partials, blocks, d_out_rows);
+  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(ABD_FIN_THREADS), 0, c->stream, c->partials, blocks, d_out_rows);
   HIP_TRY(hipGetLastError());
+  return ABD_OK;
+}
+
+int flush_ring(abd_ctx* c) {
+  if (c->ring_lo < c->ring_hi) {
+    const size_t row = (size_t)c->n_slots * ABD_NOUT;
+    const int64_t count = (int64_t)(c->ring_hi - c->ring_lo) * row;
+    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 1024);
+    hipLaunchKernelGGL(abd_copy_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_ring + (size_t)c->ring_lo * row,
+                       c->d_out + (size_t)c->ring_lo * row, count);
+    HIP_TRY(hipGetLastError());
+    c->ring_lo = c->ring_hi = 0;
+  }
   return ABD_OK;
 }
 
@@ -380,7 +395,7 @@ int check_chains(abd_ctx* c, int n, const int32_t* chains) {
   return ABD_OK;
 }
 
-int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad) {
+int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false) {
   if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
@@ -390,7 +405,18 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   r.grad = grad;
   r.chains.assign(chains, chains + n);
   r.theta.assign(theta, theta + (size_t)n * ABD_N_THETA);
-  double* rows = c->d_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  // a synchronous call lets the finalize kernel write straight into mapped host memory (one PCIe write,
+  // ~3 us inside the kernel); stream-ordered calls write device memory and are flushed together at abd_wait
+  double* rows = (deferred ? c->d_ring : c->d_out) + (size_t)slot * c->n_slots * ABD_NOUT;
+  if (deferred) {
+    if (c->ring_lo == c->ring_hi) {
+      c->ring_lo = slot;
+      c->ring_hi = slot + 1;
+    } else {
+      c->ring_lo = std::min(c->ring_lo, slot);
+      c->ring_hi = std::max(c->ring_hi, slot + 1);
+    }
+  }
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
     rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT);
@@ -510,6 +536,7 @@ void free_ctx(abd_ctx* c) {
   }
   if (c->partials) (void)hipFree(c->partials);
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->d_ring) (void)hipFree(c->d_ring);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -644,6 +671,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
+  CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   c->results.resize(kResultSlots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
@@ -703,11 +731,14 @@ int abd_n_result_slots(abd_ctx*) { return kResultSlots; }
 
 int abd_logp_dlogp_batch_enqueue(abd_ctx* c, int32_t slot, int32_t n, const int32_t* chains, const double* theta) {
   if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
-  return enqueue_slot(c, slot, n, chains, theta, true);
+  return enqueue_slot(c, slot, n, chains, theta, true, true);
 }
 
 int abd_wait(abd_ctx* c) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = flush_ring(c);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
 }
@@ -719,6 +750,7 @@ int abd_fetch(abd_ctx* c, int32_t slot, double* logp, double* grad) {
 
 int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
   if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
+  if (int frc = flush_ring(c)) return frc;
   int rc = enqueue_slot(c, 0, n, chains, theta, true);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -295,24 +295,25 @@ __device__ __forceinline__ double exp_reduced(double x) {
   return ldexp(p, (int)k);
 }
 
-// 1/d for d in [1, 2^1023): v_rcp_f64 seed + two Newton steps (relative error ~1e-16).
+// 1/d for d in [1, 2^1023): v_rcp_f64 seed (measured max rel. error 4.6e-8) + one Newton step
+// (measured 2.2e-15; a second step gives 1.1e-16 for two more fma: tools/micro/rcp_accuracy.hip).
 __device__ __forceinline__ double rcp_newton(double d) {
   double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
 
 // One observation of one antigen: logistic curve (abd.py:556-557), residual of the Normal log-term
 // (abd.py:459-469) and its raw gradient sums.  a: inflection titer at this (gap, ind); x: log_dilution; y: od.
-template <bool GRAD>
+template <bool GRAD, bool GUARD = true>
 __device__ __forceinline__ void obs_term(double a, double x, double y, double b, double d, double guard, double& q2,
                                          double& sh, double& shx, double& sqs, double& h_out) {
   const double amx = a - x;
   const double u = fmin(b * amx, 708.0);   // -b (x - a); exp stays finite, the curve is ~1e-308 there anyway
   const double e = exp_reduced(u);
   const double s = rcp_newton(1.0 + e);    // logistic / d
-  const double q = fma(-d, s, y) * guard;  // guard = 0 on padding lanes, else 1
+  double q = fma(-d, s, y);
+  if (GUARD) q *= guard;  // guard = 0 on padding lanes, else 1
   q2 = fma(q, q, q2);
   if (GRAD) {
     const double h = q * (s * (e * s));    // 1 - s = e s
@@ -527,32 +528,40 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
 
 // Fixed-order sum of the per-block partials: one block per chain.  out[chain][ABD_NOUT] may live in
 // mapped host memory (the 16 doubles per chain are the only thing that crosses PCIe per evaluation).
-__global__ __launch_bounds__(256) void abd_finalize_kernel(const double* __restrict__ partials, int n_blocks,
-                                                           double* __restrict__ out) {
-  __shared__ double sm[16][ABD_NOUT];
+#define ABD_FIN_THREADS 1024
+#define ABD_FIN_PARTS (ABD_FIN_THREADS / ABD_NOUT)  // 64
+__global__ __launch_bounds__(ABD_FIN_THREADS) void abd_finalize_kernel(const double* __restrict__ partials, int n_blocks,
+                                                                       double* __restrict__ out) {
+  __shared__ double sm[ABD_FIN_PARTS][ABD_NOUT];
   const int chain = blockIdx.x;
   const int k = threadIdx.x % ABD_NOUT;
-  const int part = threadIdx.x / ABD_NOUT;  // 0..15
+  const int part = threadIdx.x / ABD_NOUT;
   const double* p = partials + (int64_t)chain * n_blocks * ABD_NOUT;
-  // fixed summation order for a given n_blocks; 8 independent loads in flight per thread
+  // fixed summation order for a given n_blocks; 16 independent loads in flight per thread
   double v = 0.0;
-  int b = part;
-  for (; b + 7 * 16 < n_blocks; b += 8 * 16) {
-    double q[8];
+  for (int b0 = part; b0 < n_blocks; b0 += 16 * ABD_FIN_PARTS) {
+    double q[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = p[(int64_t)(b + u * 16) * ABD_NOUT + k];
+    for (int u = 0; u < 16; ++u) {
+      const int b = b0 + u * ABD_FIN_PARTS;
+      q[u] = b < n_blocks ? p[(int64_t)b * ABD_NOUT + k] : 0.0;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v += q[u];
+    for (int u = 0; u < 16; ++u) v += q[u];
   }
-  for (; b < n_blocks; b += 16) v += p[(int64_t)b * ABD_NOUT + k];
   sm[part][k] = v;
   __syncthreads();
   if (threadIdx.x < ABD_NOUT) {
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s += sm[q][threadIdx.x];
+    for (int q = 0; q < ABD_FIN_PARTS; ++q) s += sm[q][threadIdx.x];
     out[chain * ABD_NOUT + threadIdx.x] = s;
   }
+}
+
+// device result ring -> mapped host memory, for stream-ordered launches (one flush per abd_wait)
+__global__ void abd_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // (G, N) gap-major int8 (PyMC's i_raw, or vacs.T / pcrpos.T) -> packed words [nt][N]

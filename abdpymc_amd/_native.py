@@ -66,6 +66,8 @@ SYMBOLS = {
     "abd_device_name": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "abd_set_discrete": (C.c_int, [_P, C.c_int32, _I8, _I8]),
     "abd_flip_discrete": (C.c_int, [_P, C.c_int32, C.c_int64]),
+    "abd_get_discrete": (C.c_int, [_P, C.c_int32, _I8, _I8]),
+    "abd_gibbs_sweep": (C.c_int, [_P, C.c_int32, _I32, _D, C.c_uint64, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "abd_logp": (C.c_int, [_P, C.c_int32, _D, _D]),
     "abd_logp_dlogp": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
     "abd_loglik_dlogp": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
@@ -234,6 +236,25 @@ class Context:
 
     def flip_discrete(self, chain: int, flat: int):
         _check(self._lib, self._lib.abd_flip_discrete(self._h, chain, int(flat)))
+
+    def get_discrete(self, chain: int):
+        i = np.empty((self.n_gaps, self.n_inds), dtype=np.int8)
+        w = np.empty(self.n_inds, dtype=np.int8)
+        _check(self._lib, self._lib.abd_get_discrete(self._h, chain, _ptr(i, C.c_int8), _ptr(w, C.c_int8)))
+        return i, w
+
+    def gibbs_sweep(self, chains, theta, seed: int, sweep: int):
+        """One binary Gibbs-Metropolis sweep of each chain's [i_raw, ab_s_waner] in place -> (accepted, proposed)."""
+        ch = _as(np.atleast_1d(chains), np.int32)
+        t = _as(np.atleast_2d(theta), np.float64)
+        if t.shape != (ch.size, N_THETA):
+            raise ValueError(f"theta must have shape ({ch.size}, {N_THETA})")
+        acc = np.zeros(ch.size, dtype=np.int64)
+        prop = np.zeros(ch.size, dtype=np.int64)
+        _check(self._lib, self._lib.abd_gibbs_sweep(self._h, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double),
+                                                    C.c_uint64(seed & (2**64 - 1)), C.c_uint32(sweep & 0xFFFFFFFF),
+                                                    _ptr(acc, C.c_int64), _ptr(prop, C.c_int64)))
+        return acc, prop
 
     # -- evaluations ------------------------------------------------------------------------
     def logp(self, chain: int, theta) -> float:

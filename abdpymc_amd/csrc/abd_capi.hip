@@ -91,6 +91,7 @@ struct abd_ctx {
   double* partials = nullptr;  // [n_slots][blocks_max][ABD_NOUT]
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
+  unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
   int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
   std::vector<ResultSlot> results;
@@ -537,6 +538,7 @@ void free_ctx(abd_ctx* c) {
   if (c->partials) (void)hipFree(c->partials);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
+  if (c->d_counts) (void)hipFree(c->d_counts);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -672,6 +674,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
+  CREATE_TRY(hipMalloc(&c->d_counts, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
   c->results.resize(kResultSlots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
@@ -807,6 +810,82 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   if (d_n) (void)hipFree(d_n);
   if (d_s) (void)hipFree(d_s);
   if (e != hipSuccess) return fail(ABD_ERR_HIP, "deterministics: %s", hipGetErrorString(e));
+  return ABD_OK;
+}
+
+int abd_gibbs_sweep(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
+                    int64_t* accepted, int64_t* proposed) {
+  if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
+  int rc = check_chains(c, n, chains);
+  if (rc) return rc;
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (chains[a] == chains[b]) return fail(ABD_ERR_ARG, "chain %d listed twice: a sweep updates its state in place", chains[a]);
+  HIP_TRY(hipSetDevice(c->device));
+  if (int frc = flush_ring(c)) return frc;
+  std::vector<unsigned long long> counts((size_t)n * 2, 0);
+  for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
+    const int m = std::min(ABD_MAX_BATCH, n - k0);
+    GibbsArgs ga;
+    base_args(c, ga.e);
+    ga.e.n_chains = m;
+    ga.seed_lo = (uint32_t)seed;
+    ga.seed_hi = (uint32_t)(seed >> 32);
+    ga.sweep = sweep;
+    ga.pad_ = 0;
+    ga.counts = c->d_counts;
+    for (int k = 0; k < m; ++k) {
+      const double* t = theta + (size_t)(k0 + k) * ABD_N_THETA;
+      ga.e.ch[k] = chain_par(c, chains[k0 + k], t);
+      const Transformed tr = transform(t);
+      ga.theta0[k] = t[0];
+      ga.theta7[k] = t[7];
+      ga.is2_n[k] = 1.0 / (tr.sig_n * tr.sig_n);
+      ga.is2_s[k] = 1.0 / (tr.sig_s * tr.sig_s);
+    }
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, (size_t)m * 2 * sizeof(unsigned long long), c->stream));
+    const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_GIBBS_WAVE_LDS;
+    dim3 grid(blocks, m);
+    if (c->dense) {
+      if (c->storage == ABD_STORE_F32)
+        hipLaunchKernelGGL((abd_gibbs_kernel<float, true>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
+      else
+        hipLaunchKernelGGL((abd_gibbs_kernel<double, true>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
+    } else {
+      if (c->storage == ABD_STORE_F32)
+        hipLaunchKernelGGL((abd_gibbs_kernel<float, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
+      else
+        hipLaunchKernelGGL((abd_gibbs_kernel<double, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts.data() + (size_t)k0 * 2, c->d_counts, (size_t)m * 2 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  for (int k = 0; k < n; ++k) {
+    if (accepted) accepted[k] = (int64_t)counts[(size_t)k * 2];
+    if (proposed) proposed[k] = (int64_t)counts[(size_t)k * 2 + 1];
+  }
+  return ABD_OK;
+}
+
+int abd_get_discrete(abd_ctx* c, int32_t chain, int8_t* i_raw, int8_t* waner) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  int rc = check_chains(c, 1, &chain);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  ChainSlot& s = c->slots[(size_t)chain];
+  if (i_raw) {
+    dim3 grid((c->N + 255) / 256, c->G);
+    hipLaunchKernelGGL(abd_unpack_bits_kernel, grid, dim3(256), 0, c->stream, s.rw, c->stage_gn, c->G, c->N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(i_raw, c->stage_gn, (size_t)c->G * c->N, hipMemcpyDeviceToHost));
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if (waner) HIP_TRY(hipMemcpy(waner, s.waner, (size_t)c->N, hipMemcpyDeviceToHost));
   return ABD_OK;
 }
 

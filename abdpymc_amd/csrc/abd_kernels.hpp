@@ -522,6 +522,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
   }
 }
 
+#include "abd_gibbs.hpp"
+
 // ================================================================================================
 // Small kernels
 // ================================================================================================

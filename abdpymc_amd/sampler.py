@@ -177,7 +177,7 @@ def binary_gibbs_sweep(n_bits: int, flip_logp: Callable[[int], float], unflip: C
 
 
 def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_deterministics: bool = True,
-                 progress: Optional[Callable[[int, int], None]] = None) -> Dict[str, np.ndarray]:
+                 progress: Optional[Callable[[int, int], None]] = None, device_gibbs: bool = True) -> Dict[str, np.ndarray]:
     """Run tune + draws iterations of [NUTS; binary Gibbs] on chain slot ``chain`` of an AbdModel."""
     from .model import THETA_NAMES, constrain
 
@@ -199,7 +199,9 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
     nuts.da = DualAveraging(nuts.eps)
 
     n_bits = G * N + N
+    use_device_sweep = hasattr(ctx, "gibbs_sweep") and device_gibbs
 
+    # host-driven fallback (one joint-logp evaluation per proposed flip, the reference's cost model)
     def flip_logp(idx):
         ctx.flip_discrete(chain, idx)
         if idx < G * N:
@@ -229,8 +231,15 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
     for it in range(tune + draws):
         tuning = it < tune
         q, lp, g, st = nuts.step(q, lp, g, adapt=tuning)
-        lp, n_acc, n_prop = binary_gibbs_sweep(n_bits, flip_logp, unflip, lp, rng)
-        lp, g = fn(q)  # gradient at the new discrete state
+        if use_device_sweep:
+            # the whole sweep in one launch: each individual's G + 1 proposals on its own wave (abd_gibbs.hpp)
+            acc, prop = ctx.gibbs_sweep([chain], q[None, :], seed=(seed << 20) ^ 0x5EED, sweep=it)
+            n_acc, n_prop = int(acc[0]), int(prop[0])
+            if not tuning:
+                i_raw, waner = ctx.get_discrete(chain)
+        else:
+            lp, n_acc, n_prop = binary_gibbs_sweep(n_bits, flip_logp, unflip, lp, rng)
+        lp, g = fn(q)  # logp and gradient at the new discrete state
         if tuning:
             if it >= window_start:
                 window.append(q.copy())
@@ -269,12 +278,12 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
 
 
 def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
-           progress: Optional[Callable[[int, int, int], None]] = None) -> Dict[str, np.ndarray]:
+           progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True) -> Dict[str, np.ndarray]:
     """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
     if chains > model.n_chains:
         raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
     per_chain = []
     for c in range(chains):
         cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None
-        per_chain.append(sample_chain(model, c, tune, draws, seed, record_deterministics, cb))
+        per_chain.append(sample_chain(model, c, tune, draws, seed, record_deterministics, cb, device_gibbs))
     return {k: np.stack([pc[k] for pc in per_chain]) for k in per_chain[0]}

@@ -96,6 +96,17 @@ int abd_set_discrete(abd_ctx* ctx, int32_t chain, const int8_t* i_raw, const int
  * between two logp calls).  flat < G*N addresses i_raw.ravel(); flat >= G*N addresses waner[flat-G*N]. */
 int abd_flip_discrete(abd_ctx* ctx, int32_t chain, int64_t flat);
 
+/* Read the resident discrete state of `chain` back: i_raw (G, N) and waner (N,), either may be NULL. */
+int abd_get_discrete(abd_ctx* ctx, int32_t chain, int8_t* i_raw, int8_t* waner);
+
+/* One binary Gibbs-Metropolis sweep over [i_raw, ab_s_waner] of each listed chain, in place, at theta
+ * (n x 17): what PyMC's BinaryGibbsMetropolis.astep does to these two variables inside pm.sample
+ * (abd.py:922) -- every dim proposed with probability 0.8 in a uniformly random order, Metropolis
+ * acceptance on the joint logp -- using the fact that a flip only changes its own individual's terms.
+ * Randomness is Philox4x32-10 keyed by (seed, sweep).  accepted / proposed (n each) may be NULL. */
+int abd_gibbs_sweep(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta, uint64_t seed,
+                    uint32_t sweep, int64_t* accepted, int64_t* proposed);
+
 /* Scalar joint logp at (theta, resident discrete state of `chain`).  Replaces Model.compile_logp()'s
  * point function (a17). */
 int abd_logp(abd_ctx* ctx, int32_t chain, const double* theta, double* logp);

@@ -245,6 +245,157 @@ int abd_oracle_logp_dlogp(int G, int N, int n_splits, const int* splits, const i
   return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Binary Gibbs-Metropolis sweep over [i_raw, ab_s_waner]: CPU restatement of abd_gibbs_kernel
+ * (abdpymc_amd/csrc/abd_gibbs.hpp), same Philox4x32-10 stream, same order, same acceptance rule.
+ * Semantics: PyMC BinaryGibbsMetropolis.astep (transit_p = 0.8, shuffled dims, metrop_select) on the two
+ * discrete variables (abd.py:427, 373); the per-individual delta equals the joint-logp difference
+ * (tests/test_gibbs.py checks that against full joint evaluations).
+ * ------------------------------------------------------------------------------------------------- */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void abd_oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+
+typedef struct {
+  int G;
+  double perm_n, temp_n, rho_n, init_n, perm_s, rho_s, init_s, b_n, d_n, is2_n, b_s, d_s, is2_s;
+} gibbs_par;
+
+/* -1/2 sum (q/sigma)^2 of one individual's observations for infection column inf[], vaccinations vac[], waner w */
+static double individual_ll(const gibbs_par* p, const int8_t* inf, const int8_t* vac, int w, int64_t ks0, int64_t ks1,
+                            const int32_t* s_gap, const double* s_x, const double* s_y, int64_t kn0, int64_t kn1,
+                            const int32_t* n_gap, const double* n_x, const double* n_y) {
+  double mu_n[1024], mu_s[1024];
+  const double rj = p->rho_s * w + 1 - w;
+  double tn = 0, ts = 0;
+  int ci = 0, civ = 0;
+  for (int g = 0; g < p->G; ++g) {
+    tn = tn * p->rho_n + inf[g];
+    ts = ts * rj + inf[g] + vac[g];
+    ci += inf[g];
+    civ += inf[g] + vac[g];
+    mu_n[g] = (ci > 0 ? p->perm_n : 0.0) + p->temp_n * tn + p->init_n;
+    mu_s[g] = (civ > 0 ? p->perm_s : 0.0) + ts + p->init_s;
+  }
+  double acc = 0;
+  for (int64_t k = kn0; k < kn1; ++k) {
+    double q = n_y[k] - p->d_n / (1.0 + exp(-p->b_n * (n_x[k] - mu_n[n_gap[k]])));
+    acc += -0.5 * p->is2_n * q * q;
+  }
+  for (int64_t k = ks0; k < ks1; ++k) {
+    double q = s_y[k] - p->d_s / (1.0 + exp(-p->b_s * (s_x[k] - mu_s[s_gap[k]])));
+    acc += -0.5 * p->is2_s * q * q;
+  }
+  return acc;
+}
+
+/* sort one antigen's observations by individual (stable): out arrays sized K, ptr sized N+1 */
+static void csr_by_ind(int N, int64_t K, const int32_t* gap, const int32_t* ind, const double* x, const double* y,
+                       int64_t* ptr, int32_t* ogap, double* ox, double* oy) {
+  for (int j = 0; j <= N; ++j) ptr[j] = 0;
+  for (int64_t k = 0; k < K; ++k) ptr[ind[k] + 1]++;
+  for (int j = 0; j < N; ++j) ptr[j + 1] += ptr[j];
+  int64_t* cur = (int64_t*)malloc((size_t)(N + 1) * sizeof(int64_t));
+  memcpy(cur, ptr, (size_t)(N + 1) * sizeof(int64_t));
+  for (int64_t k = 0; k < K; ++k) {
+    int64_t o = cur[ind[k]]++;
+    ogap[o] = gap[k]; ox[o] = x[k]; oy[o] = y[k];
+  }
+  free(cur);
+}
+
+int abd_oracle_gibbs_sweep(int G, int N, int n_splits, const int* splits, const int8_t* vacs, const int8_t* pcrpos,
+                           int64_t K_s, const int32_t* s_gap, const int32_t* s_ind, const double* s_x, const double* s_y,
+                           int64_t K_n, const int32_t* n_gap, const int32_t* n_ind, const double* n_x, const double* n_y,
+                           int8_t* i_raw /* (G,N) in/out */, int8_t* waner /* (N) in/out */, const double* theta,
+                           int chain, uint64_t seed, uint32_t sweep, int64_t* accepted, int64_t* proposed, int nthreads) {
+  if (G < 2 || G > 1023 || N < 1 || n_splits < 0 || n_splits > 2) return -1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  gibbs_par p;
+  p.G = G;
+  p.perm_n = exp(theta[1]); p.temp_n = exp(theta[2]); p.rho_n = sigmoid(theta[3]); p.init_n = theta[4];
+  p.perm_s = exp(theta[5]); p.rho_s = sigmoid(theta[6]); p.init_s = theta[10];
+  p.b_n = theta[11]; p.d_n = theta[12]; p.is2_n = 1.0 / (exp(theta[13]) * exp(theta[13]));
+  p.b_s = theta[14]; p.d_s = theta[15]; p.is2_s = 1.0 / (exp(theta[16]) * exp(theta[16]));
+  const uint32_t k0 = (uint32_t)seed ^ (sweep * 0x9E3779B9u), k1 = (uint32_t)(seed >> 32);
+  int64_t* sp = (int64_t*)malloc((size_t)(N + 1) * 8); int64_t* np_ = (int64_t*)malloc((size_t)(N + 1) * 8);
+  int32_t* sg = (int32_t*)malloc((size_t)(K_s + 1) * 4); int32_t* ng = (int32_t*)malloc((size_t)(K_n + 1) * 4);
+  double* sx = (double*)malloc((size_t)(K_s + 1) * 8); double* sy = (double*)malloc((size_t)(K_s + 1) * 8);
+  double* nx = (double*)malloc((size_t)(K_n + 1) * 8); double* ny = (double*)malloc((size_t)(K_n + 1) * 8);
+  csr_by_ind(N, K_s, s_gap, s_ind, s_x, s_y, sp, sg, sx, sy);
+  csr_by_ind(N, K_n, n_gap, n_ind, n_x, n_y, np_, ng, nx, ny);
+  long acc_total = 0, prop_total = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : acc_total, prop_total)
+  for (int j = 0; j < N; ++j) {
+    int8_t raw[1024], rawn[1024], inf[1024], infn[1024], vac[1024];
+    const int8_t* pcr = pcrpos ? pcrpos + (size_t)j * G : 0;
+    for (int g = 0; g < G; ++g) { raw[g] = i_raw[(size_t)g * N + j]; vac[g] = vacs[(size_t)j * G + g]; }
+    int w = waner[j];
+    constrain_column(G, n_splits, splits, raw, pcr, inf);
+    /* order: rank by (word0 & ~0x1FF) | dim */
+    const int nd = G + 1;
+    uint32_t key[1025]; int order[1025]; uint32_t tr[1025], ac[1025];
+    for (int d = 0; d < nd; ++d) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)d, (uint32_t)j, (uint32_t)chain, 0u, k0, k1, r);
+      key[d] = (r[0] & ~0x1FFu) | (uint32_t)d; tr[d] = r[1]; ac[d] = r[2];
+    }
+    for (int d = 0; d < nd; ++d) {
+      int rank = 0;
+      for (int e = 0; e < nd; ++e) rank += key[e] < key[d];
+      order[rank] = d;
+    }
+    double ll = individual_ll(&p, inf, vac, w, sp[j], sp[j + 1], sg, sx, sy, np_[j], np_[j + 1], ng, nx, ny);
+    for (int k = 0; k < nd; ++k) {
+      const int d = order[k];
+      if (!(tr[d] < 3435973836u)) continue; /* transit_p = 0.8 */
+      prop_total++;
+      double delta, ll_new = ll;
+      int wn = w, same;
+      memcpy(rawn, raw, (size_t)G);
+      if (d < G) {
+        delta = raw[d] ? -theta[0] : theta[0];
+        rawn[d] ^= 1;
+        constrain_column(G, n_splits, splits, rawn, pcr, infn);
+        same = memcmp(inf, infn, (size_t)G) == 0;
+      } else {
+        wn = !w;
+        delta = wn ? theta[7] : -theta[7];
+        memcpy(infn, inf, (size_t)G);
+        same = 0;
+      }
+      if (!same) {
+        ll_new = individual_ll(&p, infn, vac, wn, sp[j], sp[j + 1], sg, sx, sy, np_[j], np_[j + 1], ng, nx, ny);
+        delta += ll_new - ll;
+      }
+      const double u = ((double)ac[d] + 0.5) * (1.0 / 4294967296.0);
+      if (delta > 0.0 || delta > log(u)) {
+        memcpy(raw, rawn, (size_t)G); memcpy(inf, infn, (size_t)G);
+        w = wn; ll = ll_new; acc_total++;
+      }
+    }
+    for (int g = 0; g < G; ++g) i_raw[(size_t)g * N + j] = raw[g];
+    waner[j] = (int8_t)w;
+  }
+  if (accepted) *accepted = acc_total;
+  if (proposed) *proposed = prop_total;
+  free(sp); free(np_); free(sg); free(ng); free(sx); free(sy); free(nx); free(ny);
+  return 0;
+}
+
 int abd_oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -134,6 +134,8 @@ def test_sampler_smoke_and_cli(tmp_path, golden_dir, test_td):
 
     m = model(test_td, n_chains=2)
     res = sample(m, tune=15, draws=10, chains=2, seed=1)
+    res_host = sample(m, tune=4, draws=3, chains=1, seed=2, device_gibbs=False)  # host-driven flips still work
+    assert res_host["i"].shape == (1, 3, 26, 10) and np.all(np.isfinite(res_host["stat_lp"]))
     assert res["p"].shape == (2, 10) and res["i"].shape == (2, 10, 26, 10) and res["ab_s_mu"].shape == (2, 10, 26, 10)
     assert np.all(np.isfinite(res["stat_lp"])) and np.all((res["p"] > 0) & (res["p"] < 1))
     # recorded Deterministic i is the constrained i_raw of the same draw

@@ -26,7 +26,7 @@ __device__ __forceinline__ uint64_t extract_bits(const uint64_t w[ABD_MAXT], int
 }
 
 template <typename R, int CB, bool GRAD>
-__global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
   // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction
   extern __shared__ __align__(16) unsigned char smem[];
   const int G = a.G, N = a.N, nt = a.nt;
@@ -51,12 +51,35 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) 
   int64_t pos = r * rows_total / n_ranges;
   const int64_t end = (r + 1) * rows_total / n_ranges;
 
-  // one wave per chain fills that chain's two power tables, the last wave the ones table
-  if (sub == 0) {
-    fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, tstride, lane);
-    fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, tstride, lane);
+  // the first two gap rows of the range are requested before anything else, so their latency hides behind
+  // the table fill and the integer pre-pass
+  const bool has_work = pos < end;
+  const int g0_first = has_work ? (int)(pos % G) : 0;
+  YX<R> pre_n0, pre_s0, pre_n1, pre_s1;
+  pre_n0.x = pre_n0.y = pre_s0.x = pre_s0.y = pre_n1.x = pre_n1.y = pre_s1.x = pre_s1.y = 0;
+  bool have_pre = false;
+  if (has_work) {
+    const int lg_f = (int)(pos / G);
+    const int j_f = min(lg_f * 64 + lane, N - 1);
+    const int g1_f = (int)min((int64_t)G, (int64_t)g0_first + (end - pos));
+    const int second = g0_first + min(1, min(64, g1_f - g0_first) - 1);
+    const YX<R>* yn = reinterpret_cast<const YX<R>*>(a.yx_n);
+    const YX<R>* ys = reinterpret_cast<const YX<R>*>(a.yx_s);
+    pre_n0 = yn[(int64_t)g0_first * N + j_f];
+    pre_s0 = ys[(int64_t)g0_first * N + j_f];
+    pre_n1 = yn[(int64_t)second * N + j_f];
+    pre_s1 = ys[(int64_t)second * N + j_f];
+    have_pre = true;
   }
-  if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, tstride, lane);
+
+  // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
+  // that starts inside an individual's gaps reads them, and only entries up to its start gap.
+  const int n_entries = CB == ABD_WAVES_PER_BLOCK ? g0_first + 1 : tstride;
+  if (sub == 0) {
+    fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
+    fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
+  }
+  if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, n_entries, lane);
 
   double acc[16];
 #pragma unroll
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) 
 
     // state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures
     double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
-    uint32_t ci = 0, civ = 0;                        // exposure-so-far flags as 0/1
+    double cf_n = 0.0, cf_s = 0.0;                   // exposure-so-far flags as 0.0 / 1.0 (abd.py:306)
     if (g0 > 0) {
       const double2_t* tab_s = wj ? tab_sw : tab_ones;
 #pragma unroll
@@ -115,8 +138,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) 
           const int rel = g0 - t * 64;  // bits < rel of word t are before the piece
           const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
           uint64_t mi = I[t] & below, mv = V[t] & below;
-          ci |= mi != 0;
-          civ |= (mi | mv) != 0;
+          if (mi != 0) cf_n = 1.0;
+          if ((mi | mv) != 0) cf_s = 1.0;
           while (mi) {  // per-lane trip count
             const int b = __builtin_ctzll(mi);
             mi &= mi - 1;
@@ -160,9 +183,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) 
         tn = fma(rho_n, tn, e_i);
         ds = fma(rho_j, ds, ts);
         ts = fma(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
-        ci |= ib;
-        civ |= ib | vb;
-        const double cf_n = (double)ci, cf_s = (double)civ;
+        cf_n = fmax(cf_n, e_i);
+        cf_s = fmax(cf_s, fmax(e_i, e_v));
         // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
         const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
         const double as = fma(cf_s, perm_s, init_s) + ts;
@@ -182,8 +204,19 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_dense_kernel(const EvalArgs a) 
 
       // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
       const int last = len - 1;
-      YX<R> n0 = row_n[j], s0 = row_s[j];
-      YX<R> n1 = row_n[(int64_t)min(1, last) * N + j], s1 = row_s[(int64_t)min(1, last) * N + j];
+      YX<R> n0, s0, n1, s1;
+      if (have_pre) {  // first chunk of the range: requested at kernel entry
+        n0 = pre_n0;
+        s0 = pre_s0;
+        n1 = pre_n1;
+        s1 = pre_s1;
+        have_pre = false;
+      } else {
+        n0 = row_n[j];
+        s0 = row_s[j];
+        n1 = row_n[(int64_t)min(1, last) * N + j];
+        s1 = row_s[(int64_t)min(1, last) * N + j];
+      }
       int gi = 0;
       for (; gi + 1 < len; gi += 2) {
         const int ga = min(gi + 2, last), gb = min(gi + 3, last);

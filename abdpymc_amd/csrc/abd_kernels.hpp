@@ -295,6 +295,25 @@ __device__ __forceinline__ double exp_reduced(double x) {
   return ldexp(p, (int)k);
 }
 
+// 2^t for t <= 1021 (callers clamp): k = rint(t), f = t - k is exact, degree-10 near-minimax polynomial for
+// 2^f on |f| <= 1/2 (tools/exp_poly.py 10 exp2: max relative error 3.1e-16), scale by 2^k.  14 VALU.
+__device__ __forceinline__ double exp2_reduced(double t) {
+  const double k = __builtin_rint(t);
+  const double f = t - k;
+  double p = 7.072585949269223e-09;
+  p = fma(p, f, 1.0208690299958306e-07);
+  p = fma(p, f, 1.321544258792169e-06);
+  p = fma(p, f, 1.5252657260200837e-05);
+  p = fma(p, f, 0.0001540353044173605);
+  p = fma(p, f, 0.0013333558230164974);
+  p = fma(p, f, 0.009618129107606888);
+  p = fma(p, f, 0.05550410866444772);
+  p = fma(p, f, 0.24022650695910097);
+  p = fma(p, f, 0.69314718055995);
+  p = fma(p, f, 1.0);
+  return ldexp(p, (int)k);
+}
+
 // 1/d for d in [1, 2^1023): v_rcp_f64 seed (measured max rel. error 4.6e-8) + one Newton step
 // (measured 2.2e-15; a second step gives 1.1e-16 for two more fma: tools/micro/rcp_accuracy.hip).
 __device__ __forceinline__ double rcp_newton(double d) {
@@ -309,8 +328,10 @@ template <bool GRAD, bool GUARD = true>
 __device__ __forceinline__ void obs_term(double a, double x, double y, double b, double d, double guard, double& q2,
                                          double& sh, double& shx, double& sqs, double& h_out) {
   const double amx = a - x;
-  const double u = fmin(b * amx, 708.0);   // -b (x - a); exp stays finite, the curve is ~1e-308 there anyway
-  const double e = exp_reduced(u);
+  // e = exp(-b (x - a)) = 2^t, t = (b log2 e)(a - x); clamped so that 1 + e stays finite (the curve is
+  // ~1e-308 of d there anyway).  b log2 e is wave-uniform and hoisted out of the gap loop.
+  const double t = fmin((b * 1.4426950408889634074) * amx, 1021.0);
+  const double e = exp2_reduced(t);
   const double s = rcp_newton(1.0 + e);    // logistic / d
   double q = fma(-d, s, y);
   if (GUARD) q *= guard;  // guard = 0 on padding lanes, else 1

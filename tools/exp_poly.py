@@ -60,3 +60,36 @@ for i in range(M):
     err = abs(p / x.exp() - 1)
     worst = max(worst, err)
 print("max rel error with double coefficients (exact Horner):", float(worst))
+
+# base-2 variant: 2^f on [-1/2, 1/2] (exp2 domain: f = t - rint(t), t = u * log2(e))
+if len(sys.argv) > 2 and sys.argv[2] == "exp2":
+    h2 = D("0.5")
+    nodes = [h2 * cos_dec(PI * (2 * i + 1) / (2 * n)) for i in range(n)]
+    vals = [(x * LN2).exp() for x in nodes]
+    coef = list(vals)
+    for jj in range(1, n):
+        for i in range(n - 1, jj - 1, -1):
+            coef[i] = (coef[i] - coef[i - 1]) / (nodes[i] - nodes[i - jj])
+    poly = [D(0)] * n
+    poly[0] = coef[n - 1]
+    cur_deg = 0
+    for i in range(n - 2, -1, -1):
+        new = [D(0)] * n
+        for k in range(cur_deg + 1):
+            new[k + 1] += poly[k]
+            new[k] -= poly[k] * nodes[i]
+        new[0] += coef[i]
+        poly = new
+        cur_deg += 1
+    cd = [float(c) for c in poly]
+    print("exp2 degree", deg)
+    for k, c in enumerate(cd):
+        print(f"  c{k} = {c!r}")
+    worst = D(0)
+    for i in range(4001):
+        x = -h2 + D(i) / D(4000)
+        p = D(0)
+        for c in reversed(cd):
+            p = p * x + D(c)
+        worst = max(worst, abs(p / (x * LN2).exp() - 1))
+    print("exp2 max rel error with double coefficients (exact Horner):", float(worst))

@@ -76,6 +76,7 @@ SYMBOLS = {
     "abd_logp_dlogp_batch_enqueue": (C.c_int, [_P, C.c_int32, C.c_int32, _I32, _D]),
     "abd_wait": (C.c_int, [_P]),
     "abd_fetch": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "abd_fetch_many": (C.c_int, [_P, C.c_int32, _I32, _D, _D]),
     "abd_deterministics": (C.c_int, [_P, C.c_int32, _D, _I8, _D, _D]),
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
@@ -316,6 +317,14 @@ class Context:
         lp = np.empty(n)
         g = np.empty((n, N_THETA))
         _check(self._lib, self._lib.abd_fetch(self._h, slot, _ptr(lp, C.c_double), _ptr(g, C.c_double)))
+        return lp, g
+
+    def fetch_many(self, slots, n_per_slot: int):
+        """fetch() for several slots at once -> (len(slots), n_per_slot) logp and (len(slots), n_per_slot, 17) grad."""
+        sl = _as(slots, np.int32)
+        lp = np.empty((sl.size, n_per_slot))
+        g = np.empty((sl.size, n_per_slot, N_THETA))
+        _check(self._lib, self._lib.abd_fetch_many(self._h, sl.size, _ptr(sl, C.c_int32), _ptr(lp, C.c_double), _ptr(g, C.c_double)))
         return lp, g
 
     def deterministics(self, chain: int, theta):

@@ -88,7 +88,16 @@ struct abd_ctx {
   uint64_t* pw = nullptr;  // [nt][N]
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
-  double* partials = nullptr;  // [n_slots][blocks_max][ABD_NOUT]
+  double* partials[2] = {nullptr, nullptr};  // [n_slots][blocks_max][ABD_NOUT], alternating per launch
+  int pbuf = 0;
+  struct {
+    bool on = false;  // the fixed-order sum of this launch's partials has not been queued yet
+    int buf = 0, n = 0, blocks = 0;
+    double* out = nullptr;
+  } pending;
+  bool fuse_finalize = true;
+  int fin_rows = 2;
+  double prior_const = 0.0;
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
@@ -142,8 +151,25 @@ Transformed transform(const double* t) {
 //   ab_n_perm/temp ~ Gamma, ab_n_rho ~ Beta(10,1), ab_n_init ~ N  abd.py:329-340
 //   ab_s_* likewise, ab_s_waner ~ Bernoulli(p_waner)               abd.py:367-388
 //   it_*_b ~ N(-1,.5), it_*_d ~ N(2,.5), it_*_sigma ~ Exp(1)       abd.py:464-467
-double priors(const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/) {
-  double lp = 0.0;
+// theta-independent part of the priors: -lnB(1, G-1) - 2 lnB(10, 1) + sum over the Gammas of
+// alpha log beta - lgamma(alpha) + the Normals' -log sd - 1/2 log 2 pi (14 lgamma calls otherwise made per
+// evaluation)
+double prior_constant(int G) {
+  double v = -(std::lgamma(1.0) + std::lgamma((double)(G - 1)) - std::lgamma((double)G));
+  v += -2.0 * (std::lgamma(10.0) + std::lgamma(1.0) - std::lgamma(11.0));
+  const double gmu[5] = {2.0, 1.0, 2.0, 1.0, 1.0};
+  for (int q = 0; q < 5; ++q) {
+    const double al = gmu[q] * gmu[q] / 0.25, be = gmu[q] / 0.25;
+    v += al * std::log(be) - std::lgamma(al);
+  }
+  const double nsd[6] = {1.0, 1.0, 0.5, 0.5, 0.5, 0.5};
+  for (int q = 0; q < 6; ++q) v += -std::log(nsd[q]) - 0.5 * kLog2Pi;
+  return v;
+}
+
+double priors(const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/,
+              double prior_const) {
+  double lp = prior_const;
   if (g) std::fill(g, g + ABD_N_THETA, 0.0);
   auto gamma_ab = [](double mu, double sd, double& a, double& b) {
     a = mu * mu / (sd * sd);
@@ -152,9 +178,7 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
   {  // theta0
     const double L0 = -softplus(-t[0]), L1 = -softplus(t[0]), p = sigmoid(t[0]);
     const double bm1 = (double)(G - 1) - 1.0;
-    // -lnB(1, G-1) = ln(G-1)
-    const double lnB = std::lgamma(1.0) + std::lgamma((double)(G - 1)) - std::lgamma((double)G);
-    lp += (bm1 == 0.0 ? 0.0 : bm1 * L1) - lnB + L0 + L1 + n1 * L0 + (cells - n1) * L1;
+    lp += (bm1 == 0.0 ? 0.0 : bm1 * L1) + L0 + L1 + n1 * L0 + (cells - n1) * L1;
     if (g) g[0] = (1.0 + n1) * (1.0 - p) - p * (bm1 + 1.0 + (cells - n1));
   }
   const int gk[5] = {1, 2, 5, 8, 9};
@@ -163,13 +187,12 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
     double al, be;
     gamma_ab(gmu[q], 0.5, al, be);
     const double x = std::exp(t[gk[q]]);
-    lp += al * std::log(be) - std::lgamma(al) + al * t[gk[q]] - be * x;
+    lp += al * t[gk[q]] - be * x;
     if (g) g[gk[q]] = al - be * x;
   }
   for (int k : {3, 6}) {
     const double L0 = -softplus(-t[k]), L1 = -softplus(t[k]), r = sigmoid(t[k]);
-    const double lnB = std::lgamma(10.0) + std::lgamma(1.0) - std::lgamma(11.0);
-    lp += 9.0 * L0 - lnB + L0 + L1;
+    lp += 9.0 * L0 + L0 + L1;
     if (g) g[k] = 10.0 * (1.0 - r) - r;
   }
   {
@@ -182,7 +205,7 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
   const double nsd[6] = {1.0, 1.0, 0.5, 0.5, 0.5, 0.5};
   for (int q = 0; q < 6; ++q) {
     const double z = (t[nk[q]] - nmu[q]) / nsd[q];
-    lp += -0.5 * z * z - std::log(nsd[q]) - 0.5 * kLog2Pi;
+    lp += -0.5 * z * z;
     if (g) g[nk[q]] = -z / nsd[q];
   }
   for (int k : {13, 16}) {
@@ -202,7 +225,7 @@ void assemble(const abd_ctx* c, const double* t, const double* sums, double* log
   const double cells = (double)c->G * (double)c->N;
   double lp = 0.0;
   if (with_priors)
-    lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad);
+    lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad, c->prior_const);
   else if (grad)
     std::fill(grad, grad + ABD_N_THETA, 0.0);
   const double Kn = (double)c->n.K, Ks = (double)c->s.K;
@@ -261,7 +284,6 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.yx_s = c->s.yx;
   a.vw = c->vw;
   a.pw = c->ignore_pcr ? nullptr : c->pw;
-  a.partials = c->partials;
   a.G = c->G;
   a.N = c->N;
   a.nt = c->nt;
@@ -271,7 +293,8 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
 }
 
 size_t table_lds_bytes(int G, int cpw, int red_rows) {
-  return (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double);
+  return std::max<size_t>(ABD_FIN_PARTS * ABD_NOUT * sizeof(double),  // finalize scratch of the fused form
+                          (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double));
 }
 
 template <typename K>
@@ -328,6 +351,17 @@ int dense_blocks(const abd_ctx* c, int cpw) {
   return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)c->dense_blocks, cap, (int64_t)c->blocks_max}));
 }
 
+// queue the standalone fixed-order sum of a launch whose partials are still pending
+int flush_pending(abd_ctx* c) {
+  if (c->pending.on) {
+    hipLaunchKernelGGL(abd_finalize_kernel, dim3(c->pending.n), dim3(ABD_FIN_THREADS), 0, c->stream,
+                       c->partials[c->pending.buf], c->pending.blocks, c->pending.out);
+    HIP_TRY(hipGetLastError());
+    c->pending.on = false;
+  }
+  return ABD_OK;
+}
+
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows) {
   EvalArgs a;
@@ -346,6 +380,21 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
   dim3 grid(blocks, n / cpw);
+  const int buf = c->pbuf;
+  c->pbuf ^= 1;
+  a.partials = c->partials[buf];
+  a.fin_rows = c->fin_rows;
+  if (c->dense && c->fuse_finalize && c->pending.on && c->pending.n <= blocks) {
+    // this launch's first workgroups sum the previous launch's partials
+    a.prev_partials = c->partials[c->pending.buf];
+    a.prev_out = c->pending.out;
+    a.prev_n_chains = c->pending.n;
+    a.prev_blocks = c->pending.blocks;
+    c->pending.on = false;
+  } else {
+    int frc = flush_pending(c);
+    if (frc) return frc;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -368,12 +417,17 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
                                      : launch_sparse<double>(cpw, grad, grid, lds, c->stream, a);
   if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(le);
-  hipLaunchKernelGGL(abd_finalize_kernel, dim3(n), dim3(ABD_FIN_THREADS), 0, c->stream, c->partials, blocks, d_out_rows);
-  HIP_TRY(hipGetLastError());
+  c->pending.on = true;
+  c->pending.buf = buf;
+  c->pending.n = n;
+  c->pending.blocks = blocks;
+  c->pending.out = d_out_rows;
+  if (!(c->dense && c->fuse_finalize)) return flush_pending(c);
   return ABD_OK;
 }
 
 int flush_ring(abd_ctx* c) {
+  if (int prc = flush_pending(c)) return prc;
   if (c->ring_lo < c->ring_hi) {
     const size_t row = (size_t)c->n_slots * ABD_NOUT;
     const int64_t count = (int64_t)(c->ring_hi - c->ring_lo) * row;
@@ -535,7 +589,8 @@ void free_ctx(abd_ctx* c) {
     if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
   }
-  if (c->partials) (void)hipFree(c->partials);
+  for (int b = 0; b < 2; ++b)
+    if (c->partials[b]) (void)hipFree(c->partials[b]);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
@@ -589,6 +644,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->G = G;
   c->N = N;
   c->nt = (G + 63) / 64;
+  c->prior_const = prior_constant(G);
   c->n_lg = (N + 63) / 64;
   c->n_chunks = d->n_splits + 1;
   c->storage = d->storage;
@@ -668,7 +724,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     CREATE_TRY(hipMalloc(&s.rw, words * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
   }
-  CREATE_TRY(hipMalloc(&c->partials, (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
+  for (int b = 0; b < 2; ++b) CREATE_TRY(hipMalloc(&c->partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
+  if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
   const size_t out_bytes = (size_t)kResultSlots * c->n_slots * ABD_NOUT * sizeof(double);
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
   std::memset(c->h_out, 0, out_bytes);
@@ -751,11 +809,25 @@ int abd_fetch(abd_ctx* c, int32_t slot, double* logp, double* grad) {
   return fetch_slot(c, slot, logp, grad);
 }
 
+int abd_fetch_many(abd_ctx* c, int32_t n_slots, const int32_t* slots, double* logp, double* grad) {
+  if (!c || !slots || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  size_t off = 0;
+  for (int s = 0; s < n_slots; ++s) {
+    if (slots[s] < 0 || slots[s] >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slots[s], kResultSlots);
+    const int n = c->results[slots[s]].n;
+    int rc = fetch_slot(c, slots[s], logp + off, grad ? grad + off * ABD_N_THETA : nullptr);
+    if (rc) return rc;
+    off += (size_t)n;
+  }
+  return ABD_OK;
+}
+
 int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
   if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
   if (int frc = flush_ring(c)) return frc;
   int rc = enqueue_slot(c, 0, n, chains, theta, true);
   if (rc) return rc;
+  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
   HIP_TRY(hipStreamSynchronize(c->stream));
   return fetch_slot(c, 0, logp, grad);
 }
@@ -768,6 +840,7 @@ int abd_loglik_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* log
   if (!c || !theta || !loglik || !grad) return fail(ABD_ERR_ARG, "NULL argument");
   int rc = enqueue_slot(c, 0, 1, &chain, theta, true);
   if (rc) return rc;
+  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
   HIP_TRY(hipStreamSynchronize(c->stream));
   return fetch_slot(c, 0, loglik, grad, false);
 }
@@ -776,6 +849,7 @@ int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {
   if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
   int rc = enqueue_slot(c, 0, 1, &chain, theta, false);
   if (rc) return rc;
+  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
   HIP_TRY(hipStreamSynchronize(c->stream));
   return fetch_slot(c, 0, logp, nullptr);
 }

@@ -44,12 +44,23 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const int cbase = blockIdx.y * CB;
   const ChainPar& p = a.ch[cbase + c];
 
-  // this wave's range of the flattened (lane group, gap) plane
+  // the first workgroups of grid row 0 first sum the previous launch's partials (see EvalArgs::prev_*)
+  const int n_fin = blockIdx.y == 0 ? a.prev_n_chains : 0;
+  if ((int)blockIdx.x < n_fin) {
+    finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blockIdx.x * a.prev_blocks * ABD_NOUT, a.prev_blocks,
+                   a.prev_out + (int64_t)blockIdx.x * ABD_NOUT, reinterpret_cast<double*>(smem), tid);
+    __syncthreads();  // the scratch becomes the power tables
+  }
+
+  // this wave's range of the flattened (lane group, gap) plane; ranges of finalizing workgroups are
+  // fin_rows shorter (one range per workgroup only: CB == 4), the others share the difference
   const int64_t rows_total = (int64_t)a.n_lg * G;
   const int64_t n_ranges = (int64_t)gridDim.x * NSUB;
   const int64_t r = (int64_t)blockIdx.x * NSUB + sub;
-  int64_t pos = r * rows_total / n_ranges;
-  const int64_t end = (r + 1) * rows_total / n_ranges;
+  const int64_t e_fin = (NSUB == 1 && (rows_total + (int64_t)n_fin * a.fin_rows) / n_ranges >= 2 * a.fin_rows) ? a.fin_rows : 0;
+  const int64_t virt = rows_total + n_fin * e_fin;
+  int64_t pos = r * virt / n_ranges - e_fin * min(r, (int64_t)n_fin);
+  const int64_t end = (r + 1) * virt / n_ranges - e_fin * min(r + 1, (int64_t)n_fin);
 
   // the first two gap rows of the range are requested before anything else, so their latency hides behind
   // the table fill and the integer pre-pass

@@ -82,6 +82,13 @@ struct EvalArgs {
   const uint64_t* vw;
   const uint64_t* pw;  // nullptr = ignore_pcrpos
   double* partials;    // [n_chains][grid.x][ABD_NOUT]
+  // dense kernel only: the fixed-order sum of the PREVIOUS launch's partials, done by the first
+  // prev_n_chains workgroups of this launch (saves a kernel and a boundary per step when launches are
+  // stream-ordered); prev_n_chains = 0 -> nothing to do
+  const double* prev_partials;
+  double* prev_out;
+  int32_t prev_n_chains, prev_blocks;
+  int32_t fin_rows, pad2_;  // gap rows the finalizing workgroups are excused from
   int32_t G, N, nt, n_chunks;
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
   uint64_t chunk_mask[3][ABD_MAXT];
@@ -349,6 +356,40 @@ __device__ __forceinline__ void obs_term(double a, double x, double y, double b,
 // Dense-panel kernel: lane = individual, wave = (64 individuals, chain, gap segment)
 // ================================================================================================
 
+// Fixed-order sum of one chain's per-block partials by one workgroup of NT threads: 64 interleaved partial
+// sums (block b goes to partial b mod 64; 16 independent loads in flight per thread), then a 64-way sum per
+// value.  The order depends only on n_blocks -- not on NT -- so the standalone kernel (1024 threads) and the
+// fused form inside the next dense launch (256 threads, abd_dense.hpp) give identical bits.
+// sm: 64 x ABD_NOUT doubles of LDS scratch.  out may live in mapped host memory (the 16 doubles per chain
+// are the only thing that crosses PCIe per evaluation).
+#define ABD_FIN_PARTS 64
+template <int NT>
+__device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int n_blocks, double* __restrict__ out,
+                                               double* sm, int tid) {
+  const int k = tid % ABD_NOUT;
+  for (int part = tid / ABD_NOUT; part < ABD_FIN_PARTS; part += NT / ABD_NOUT) {
+    double v = 0.0;
+    for (int b0 = part; b0 < n_blocks; b0 += 16 * ABD_FIN_PARTS) {
+      double q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * ABD_FIN_PARTS;
+        q[u] = b < n_blocks ? p[(int64_t)b * ABD_NOUT + k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += q[u];
+    }
+    sm[part * ABD_NOUT + k] = v;
+  }
+  __syncthreads();
+  if (tid < ABD_NOUT) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < ABD_FIN_PARTS; ++q) t += sm[q * ABD_NOUT + tid];
+    out[tid] = t;
+  }
+}
+
 #include "abd_dense.hpp"
 
 // ================================================================================================
@@ -549,37 +590,12 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
 // Small kernels
 // ================================================================================================
 
-// Fixed-order sum of the per-block partials: one block per chain.  out[chain][ABD_NOUT] may live in
-// mapped host memory (the 16 doubles per chain are the only thing that crosses PCIe per evaluation).
 #define ABD_FIN_THREADS 1024
-#define ABD_FIN_PARTS (ABD_FIN_THREADS / ABD_NOUT)  // 64
 __global__ __launch_bounds__(ABD_FIN_THREADS) void abd_finalize_kernel(const double* __restrict__ partials, int n_blocks,
                                                                        double* __restrict__ out) {
-  __shared__ double sm[ABD_FIN_PARTS][ABD_NOUT];
-  const int chain = blockIdx.x;
-  const int k = threadIdx.x % ABD_NOUT;
-  const int part = threadIdx.x / ABD_NOUT;
-  const double* p = partials + (int64_t)chain * n_blocks * ABD_NOUT;
-  // fixed summation order for a given n_blocks; 16 independent loads in flight per thread
-  double v = 0.0;
-  for (int b0 = part; b0 < n_blocks; b0 += 16 * ABD_FIN_PARTS) {
-    double q[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int b = b0 + u * ABD_FIN_PARTS;
-      q[u] = b < n_blocks ? p[(int64_t)b * ABD_NOUT + k] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v += q[u];
-  }
-  sm[part][k] = v;
-  __syncthreads();
-  if (threadIdx.x < ABD_NOUT) {
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < ABD_FIN_PARTS; ++q) s += sm[q][threadIdx.x];
-    out[chain * ABD_NOUT + threadIdx.x] = s;
-  }
+  __shared__ double sm[ABD_FIN_PARTS * ABD_NOUT];
+  finalize_chain<ABD_FIN_THREADS>(partials + (int64_t)blockIdx.x * n_blocks * ABD_NOUT, n_blocks,
+                                  out + blockIdx.x * ABD_NOUT, sm, threadIdx.x);
 }
 
 // device result ring -> mapped host memory, for stream-ordered launches (one flush per abd_wait)

@@ -108,11 +108,10 @@ def main():
             for k in range(s, e):
                 ctx.enqueue(k - s, chains, thetas[k])
             ctx.wait()
-            for k in range(s, e):
-                lp, g = ctx.fetch(k - s, C)
-                if out_lp is not None:
-                    out_lp[k - lo] = lp
-                    out_g[k - lo] = g
+            lp, g = ctx.fetch_many(np.arange(e - s), C)  # host side: prior terms + scaling of the device sums
+            if out_lp is not None:
+                out_lp[s - lo:e - lo] = lp
+                out_g[s - lo:e - lo] = g
             s = e
 
     # ---- warm-up ----

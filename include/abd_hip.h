@@ -132,6 +132,8 @@ int abd_logp_dlogp_batch_enqueue(abd_ctx* ctx, int32_t slot, int32_t n, const in
                                  const double* theta);
 int abd_wait(abd_ctx* ctx);
 int abd_fetch(abd_ctx* ctx, int32_t slot, double* logp, double* grad);
+/* abd_fetch for several slots in one call; outputs are concatenated in the order of `slots`. */
+int abd_fetch_many(abd_ctx* ctx, int32_t n_slots, const int32_t* slots, double* logp, double* grad);
 
 /* The three recorded Deterministics for chain slot `chain` at theta, each (G, N) row-major as PyMC
  * stores them (dims gap, ind).  Any output pointer may be NULL. */

@@ -94,7 +94,9 @@ struct abd_ctx {
     bool on = false;  // the fixed-order sum of this launch's partials has not been queued yet
     int buf = 0, n = 0, blocks = 0;
     double* out = nullptr;
+    double tag = 0.0;
   } pending;
+  double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
   int fin_rows = 2;
   double prior_const = 0.0;
@@ -355,7 +357,7 @@ int dense_blocks(const abd_ctx* c, int cpw) {
 int flush_pending(abd_ctx* c) {
   if (c->pending.on) {
     hipLaunchKernelGGL(abd_finalize_kernel, dim3(c->pending.n), dim3(ABD_FIN_THREADS), 0, c->stream,
-                       c->partials[c->pending.buf], c->pending.blocks, c->pending.out);
+                       c->partials[c->pending.buf], c->pending.blocks, c->pending.out, c->pending.tag);
     HIP_TRY(hipGetLastError());
     c->pending.on = false;
   }
@@ -390,6 +392,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     a.prev_out = c->pending.out;
     a.prev_n_chains = c->pending.n;
     a.prev_blocks = c->pending.blocks;
+    a.prev_tag = c->pending.tag;
     c->pending.on = false;
   } else {
     int frc = flush_pending(c);
@@ -422,6 +425,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   c->pending.n = n;
   c->pending.blocks = blocks;
   c->pending.out = d_out_rows;
+  c->seq += 1.0;
+  c->pending.tag = c->seq;
   if (!(c->dense && c->fuse_finalize)) return flush_pending(c);
   return ABD_OK;
 }
@@ -437,6 +442,22 @@ int flush_ring(abd_ctx* c) {
     HIP_TRY(hipGetLastError());
     c->ring_lo = c->ring_hi = 0;
   }
+  return ABD_OK;
+}
+
+// Wait for the rows of a synchronous call (written into mapped host memory) by polling their completion tag;
+// falls back to a stream synchronise if it does not show up quickly.
+int wait_rows(abd_ctx* c, int slot, int n, double tag) {
+  volatile const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  const int k = n - 1;  // groups complete in order on the stream: the last row's tag is the last to land
+  for (int spin = 0; spin < 2000000; ++spin) {
+    if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] == tag) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return ABD_OK;
+    }
+    __builtin_ia32_pause();
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
 }
 
@@ -828,7 +849,7 @@ int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const dou
   int rc = enqueue_slot(c, 0, n, chains, theta, true);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
   return fetch_slot(c, 0, logp, grad);
 }
 
@@ -841,7 +862,7 @@ int abd_loglik_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* log
   int rc = enqueue_slot(c, 0, 1, &chain, theta, true);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
   return fetch_slot(c, 0, loglik, grad, false);
 }
 
@@ -850,7 +871,7 @@ int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {
   int rc = enqueue_slot(c, 0, 1, &chain, theta, false);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
   return fetch_slot(c, 0, logp, nullptr);
 }
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const int n_fin = blockIdx.y == 0 ? a.prev_n_chains : 0;
   if ((int)blockIdx.x < n_fin) {
     finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blockIdx.x * a.prev_blocks * ABD_NOUT, a.prev_blocks,
-                   a.prev_out + (int64_t)blockIdx.x * ABD_NOUT, reinterpret_cast<double*>(smem), tid);
+                   a.prev_out + (int64_t)blockIdx.x * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.prev_tag);
     __syncthreads();  // the scratch becomes the power tables
   }
 

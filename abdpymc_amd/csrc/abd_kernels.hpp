@@ -89,6 +89,7 @@ struct EvalArgs {
   double* prev_out;
   int32_t prev_n_chains, prev_blocks;
   int32_t fin_rows, pad2_;  // gap rows the finalizing workgroups are excused from
+  double prev_tag;          // completion tag of the previous launch (see finalize_chain)
   int32_t G, N, nt, n_chunks;
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
   uint64_t chunk_mask[3][ABD_MAXT];
@@ -365,7 +366,7 @@ __device__ __forceinline__ void obs_term(double a, double x, double y, double b,
 #define ABD_FIN_PARTS 64
 template <int NT>
 __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int n_blocks, double* __restrict__ out,
-                                               double* sm, int tid) {
+                                               double* sm, int tid, double tag) {
   const int k = tid % ABD_NOUT;
   for (int part = tid / ABD_NOUT; part < ABD_FIN_PARTS; part += NT / ABD_NOUT) {
     double v = 0.0;
@@ -382,11 +383,21 @@ __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int
     sm[part * ABD_NOUT + k] = v;
   }
   __syncthreads();
+  double t = 0.0;
   if (tid < ABD_NOUT) {
-    double t = 0.0;
 #pragma unroll
     for (int q = 0; q < ABD_FIN_PARTS; ++q) t += sm[q * ABD_NOUT + tid];
-    out[tid] = t;
+  }
+  __syncthreads();
+  if (tid < ABD_NOUT) sm[tid] = t;
+  __syncthreads();
+  if (tid == 0) {
+    // one lane writes the row, then -- behind a system-scope fence -- the launch's tag into the spare 16th
+    // double: a host that polls the tag in mapped memory sees a complete row without a stream synchronise
+#pragma unroll
+    for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];
+    __threadfence_system();
+    out[ABD_NOUT - 1] = tag;
   }
 }
 
@@ -592,10 +603,10 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
 
 #define ABD_FIN_THREADS 1024
 __global__ __launch_bounds__(ABD_FIN_THREADS) void abd_finalize_kernel(const double* __restrict__ partials, int n_blocks,
-                                                                       double* __restrict__ out) {
+                                                                       double* __restrict__ out, double tag) {
   __shared__ double sm[ABD_FIN_PARTS * ABD_NOUT];
   finalize_chain<ABD_FIN_THREADS>(partials + (int64_t)blockIdx.x * n_blocks * ABD_NOUT, n_blocks,
-                                  out + blockIdx.x * ABD_NOUT, sm, threadIdx.x);
+                                  out + blockIdx.x * ABD_NOUT, sm, threadIdx.x, tag);
 }
 
 // device result ring -> mapped host memory, for stream-ordered launches (one flush per abd_wait)

@@ -707,8 +707,8 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_BLOCKS_PER_CU")) bpc = std::max(1, std::atoi(e));
   const int sparse_max = std::max(1, std::min((N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 16));
   c->blocks_x = std::max(1, std::min(sparse_max, c->n_cu * bpc));
-  // dense kernel: 5 workgroups per CU (<= 96 VGPRs, ~29 KB LDS each)
-  int dbpc = 5;
+  // dense kernel: 4 workgroups per CU = 4 waves per SIMD (<= 128 VGPRs, ~29 KB LDS each): one round, equal ranges
+  int dbpc = 4;
   if (const char* e = std::getenv("ABD_DENSE_BLOCKS_PER_CU")) dbpc = std::max(1, std::atoi(e));
   c->blocks_max = std::max(sparse_max, c->n_cu * 16);
   c->dense_blocks = std::min(c->n_cu * dbpc, c->blocks_max);

@@ -62,26 +62,8 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   int64_t pos = r * virt / n_ranges - e_fin * min(r, (int64_t)n_fin);
   const int64_t end = (r + 1) * virt / n_ranges - e_fin * min(r + 1, (int64_t)n_fin);
 
-  // the first two gap rows of the range are requested before anything else, so their latency hides behind
-  // the table fill and the integer pre-pass
   const bool has_work = pos < end;
   const int g0_first = has_work ? (int)(pos % G) : 0;
-  YX<R> pre_n0, pre_s0, pre_n1, pre_s1;
-  pre_n0.x = pre_n0.y = pre_s0.x = pre_s0.y = pre_n1.x = pre_n1.y = pre_s1.x = pre_s1.y = 0;
-  bool have_pre = false;
-  if (has_work) {
-    const int lg_f = (int)(pos / G);
-    const int j_f = min(lg_f * 64 + lane, N - 1);
-    const int g1_f = (int)min((int64_t)G, (int64_t)g0_first + (end - pos));
-    const int second = g0_first + min(1, min(64, g1_f - g0_first) - 1);
-    const YX<R>* yn = reinterpret_cast<const YX<R>*>(a.yx_n);
-    const YX<R>* ys = reinterpret_cast<const YX<R>*>(a.yx_s);
-    pre_n0 = yn[(int64_t)g0_first * N + j_f];
-    pre_s0 = ys[(int64_t)g0_first * N + j_f];
-    pre_n1 = yn[(int64_t)second * N + j_f];
-    pre_s1 = ys[(int64_t)second * N + j_f];
-    have_pre = true;
-  }
 
   // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
   // that starts inside an individual's gaps reads them, and only entries up to its start gap.
@@ -215,19 +197,8 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
 
       // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
       const int last = len - 1;
-      YX<R> n0, s0, n1, s1;
-      if (have_pre) {  // first chunk of the range: requested at kernel entry
-        n0 = pre_n0;
-        s0 = pre_s0;
-        n1 = pre_n1;
-        s1 = pre_s1;
-        have_pre = false;
-      } else {
-        n0 = row_n[j];
-        s0 = row_s[j];
-        n1 = row_n[(int64_t)min(1, last) * N + j];
-        s1 = row_s[(int64_t)min(1, last) * N + j];
-      }
+      YX<R> n0 = row_n[j], s0 = row_s[j];
+      YX<R> n1 = row_n[(int64_t)min(1, last) * N + j], s1 = row_s[(int64_t)min(1, last) * N + j];
       int gi = 0;
       for (; gi + 1 < len; gi += 2) {
         const int ga = min(gi + 2, last), gb = min(gi + 3, last);

@@ -42,6 +42,7 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int kResultSlots = 1024;
+constexpr int kSyncSlot = kResultSlots;  // private rows of the synchronous calls: they never touch a caller's slot
 constexpr int kMinRows = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
@@ -100,7 +101,7 @@ struct abd_ctx {
   bool fuse_finalize = true;
   int fin_rows = 2;
   double prior_const = 0.0;
-  double* h_out = nullptr;     // pinned + mapped: [kResultSlots][n_slots][ABD_NOUT]
+  double* h_out = nullptr;     // pinned + mapped: [kResultSlots + 1][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
@@ -472,7 +473,7 @@ int check_chains(abd_ctx* c, int n, const int32_t* chains) {
 }
 
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false) {
-  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  if (slot < 0 || slot > kSyncSlot) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
@@ -502,7 +503,7 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true) {
-  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  if (slot < 0 || slot > kSyncSlot) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   const ResultSlot& r = c->results[slot];
   if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
   const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
@@ -748,13 +749,13 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   for (int b = 0; b < 2; ++b) CREATE_TRY(hipMalloc(&c->partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
   if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
-  const size_t out_bytes = (size_t)kResultSlots * c->n_slots * ABD_NOUT * sizeof(double);
+  const size_t out_bytes = (size_t)(kResultSlots + 1) * c->n_slots * ABD_NOUT * sizeof(double);
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   CREATE_TRY(hipMalloc(&c->d_counts, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
-  c->results.resize(kResultSlots);
+  c->results.resize(kResultSlots + 1);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -813,6 +814,7 @@ int abd_n_result_slots(abd_ctx*) { return kResultSlots; }
 
 int abd_logp_dlogp_batch_enqueue(abd_ctx* c, int32_t slot, int32_t n, const int32_t* chains, const double* theta) {
   if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
+  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   return enqueue_slot(c, slot, n, chains, theta, true, true);
 }
 
@@ -827,6 +829,7 @@ int abd_wait(abd_ctx* c) {
 
 int abd_fetch(abd_ctx* c, int32_t slot, double* logp, double* grad) {
   if (!c || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  if (slot < 0 || slot >= kResultSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   return fetch_slot(c, slot, logp, grad);
 }
 
@@ -846,11 +849,11 @@ int abd_fetch_many(abd_ctx* c, int32_t n_slots, const int32_t* slots, double* lo
 int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
   if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
   if (int frc = flush_ring(c)) return frc;
-  int rc = enqueue_slot(c, 0, n, chains, theta, true);
+  int rc = enqueue_slot(c, kSyncSlot, n, chains, theta, true);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
-  return fetch_slot(c, 0, logp, grad);
+  if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
+  return fetch_slot(c, kSyncSlot, logp, grad);
 }
 
 int abd_logp_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* logp, double* grad) {
@@ -859,20 +862,20 @@ int abd_logp_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* logp,
 
 int abd_loglik_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* loglik, double* grad) {
   if (!c || !theta || !loglik || !grad) return fail(ABD_ERR_ARG, "NULL argument");
-  int rc = enqueue_slot(c, 0, 1, &chain, theta, true);
+  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, true);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
-  return fetch_slot(c, 0, loglik, grad, false);
+  if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
+  return fetch_slot(c, kSyncSlot, loglik, grad, false);
 }
 
 int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {
   if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
-  int rc = enqueue_slot(c, 0, 1, &chain, theta, false);
+  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, false);
   if (rc) return rc;
   if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
-  if (int wrc = wait_rows(c, 0, c->results[0].n, c->seq)) return wrc;
-  return fetch_slot(c, 0, logp, nullptr);
+  if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
+  return fetch_slot(c, kSyncSlot, logp, nullptr);
 }
 
 int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i, double* mu_n, double* mu_s) {

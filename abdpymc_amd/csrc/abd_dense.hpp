@@ -52,15 +52,18 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     __syncthreads();  // the scratch becomes the power tables
   }
 
-  // this wave's range of the flattened (lane group, gap) plane; ranges of finalizing workgroups are
-  // fin_rows shorter (one range per workgroup only: CB == 4), the others share the difference
+  // this wave's range of the flattened (lane group, gap) plane.  The workgroups that may carry a fused sum
+  // (the first n_chains of grid row 0; one range per workgroup only: CB == 4) get ranges fin_rows shorter,
+  // the others share the difference.  The split depends only on the launch shape, never on whether a sum is
+  // actually carried, so results are bit-identical either way.
   const int64_t rows_total = (int64_t)a.n_lg * G;
   const int64_t n_ranges = (int64_t)gridDim.x * NSUB;
   const int64_t r = (int64_t)blockIdx.x * NSUB + sub;
-  const int64_t e_fin = (NSUB == 1 && (rows_total + (int64_t)n_fin * a.fin_rows) / n_ranges >= 2 * a.fin_rows) ? a.fin_rows : 0;
-  const int64_t virt = rows_total + n_fin * e_fin;
-  int64_t pos = r * virt / n_ranges - e_fin * min(r, (int64_t)n_fin);
-  const int64_t end = (r + 1) * virt / n_ranges - e_fin * min(r + 1, (int64_t)n_fin);
+  const int64_t n_short = blockIdx.y == 0 ? min((int64_t)a.n_chains, n_ranges) : 0;
+  const int64_t e_fin = (NSUB == 1 && (rows_total + n_short * a.fin_rows) / n_ranges >= 2 * a.fin_rows) ? a.fin_rows : 0;
+  const int64_t virt = rows_total + n_short * e_fin;
+  int64_t pos = r * virt / n_ranges - e_fin * min(r, n_short);
+  const int64_t end = (r + 1) * virt / n_ranges - e_fin * min(r + 1, n_short);
 
   const bool has_work = pos < end;
   const int g0_first = has_work ? (int)(pos % G) : 0;

@@ -282,27 +282,6 @@ __device__ __forceinline__ double ld(const void* p, int64_t k) {
   return (double)reinterpret_cast<const R*>(p)[k];
 }
 
-// exp(x) for x <= 708 (callers clamp): Cody-Waite reduction by ln 2, degree-10 near-minimax polynomial
-// on |f| <= ln2/2 (interpolation at Chebyshev nodes, tools/exp_poly.py: max relative error 3.3e-16),
-// scale by 2^k.  15 VALU, no special-case branches.
-__device__ __forceinline__ double exp_reduced(double x) {
-  const double k = __builtin_rint(x * 1.4426950408889634074);
-  double f = fma(k, -6.93147180369123816490e-01, x);
-  f = fma(k, -1.90821492927058770002e-10, f);
-  double p = 2.7626357241447223e-07;
-  p = fma(p, f, 2.764018079620985e-06);
-  p = fma(p, f, 2.4801504346997686e-05);
-  p = fma(p, f, 0.00019841170270440067);
-  p = fma(p, f, 0.0013888888932488599);
-  p = fma(p, f, 0.008333333385667782);
-  p = fma(p, f, 0.04166666666657314);
-  p = fma(p, f, 0.16666666666554406);
-  p = fma(p, f, 0.5000000000000006);
-  p = fma(p, f, 1.0000000000000067);
-  p = fma(p, f, 1.0);
-  return ldexp(p, (int)k);
-}
-
 // 2^t for t <= 1021 (callers clamp): k = rint(t), f = t - k is exact, degree-10 near-minimax polynomial for
 // 2^f on |f| <= 1/2 (tools/exp_poly.py 10 exp2: max relative error 3.1e-16), scale by 2^k.  14 VALU.
 __device__ __forceinline__ double exp2_reduced(double t) {

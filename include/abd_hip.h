@@ -126,7 +126,9 @@ int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const d
 
 /* Stream-ordered form: enqueue returns as soon as the launch is queued; results land in result slot
  * `slot` (0 <= slot < abd_n_result_slots) and are read back with abd_fetch after abd_wait.
- * A NUTS driver that runs several chain groups uses this to overlap host work with the device. */
+ * A NUTS driver that runs several chain groups uses this to overlap host work with the device.
+ * Synchronous calls may be interleaved: they use rows of their own and leave every result slot alone;
+ * both forms return identical bits for the same (chains, theta). */
 int abd_n_result_slots(abd_ctx* ctx);
 int abd_logp_dlogp_batch_enqueue(abd_ctx* ctx, int32_t slot, int32_t n, const int32_t* chains,
                                  const double* theta);

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -51,6 +52,22 @@ class _Desc(C.Structure):
     ]
 
 
+class _SamplerOpts(C.Structure):
+    _fields_ = [
+        ("tune", C.c_int64),
+        ("seed", C.c_uint64),
+        ("target_accept", C.c_double),
+        ("max_treedepth", C.c_int32),
+        ("gibbs", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+N_STATS = 10
+STAT_NAMES = ("lp", "tree_depth", "n_steps", "mean_tree_accept", "step_size", "diverging", "energy", "max_energy_error",
+              "gibbs_accepted", "gibbs_proposed")
+
 _lib = None
 
 # every symbol include/abd_hip.h declares: name -> (restype, argtypes)
@@ -78,6 +95,11 @@ SYMBOLS = {
     "abd_fetch": (C.c_int, [_P, C.c_int32, _D, _D]),
     "abd_fetch_many": (C.c_int, [_P, C.c_int32, _I32, _D, _D]),
     "abd_deterministics": (C.c_int, [_P, C.c_int32, _D, _I8, _D, _D]),
+    "abd_sampler_create": (C.c_int, [_P, C.c_int32, _I32, _D, C.POINTER(_SamplerOpts), C.POINTER(_P)]),
+    "abd_sampler_destroy": (None, [_P]),
+    "abd_sampler_run": (C.c_int, [_P, C.c_int64, _D, _D]),
+    "abd_sampler_means": (C.c_int, [_P, C.c_int32, _D, _D, _D, C.POINTER(C.c_int64)]),
+    "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D]),
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
@@ -149,6 +171,7 @@ class Context:
         lib = load()
         self._lib = lib
         self._h = _P()
+        self._samplers = weakref.WeakSet()  # destroyed before the context they point into
         self.n_gaps, self.n_inds, self.n_chains = int(n_gaps), int(n_inds), int(n_chains)
         d = _Desc()
         d.n_gaps, d.n_inds = self.n_gaps, self.n_inds
@@ -200,6 +223,8 @@ class Context:
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            for smp in list(self._samplers):
+                smp.close()
             self._lib.abd_destroy(self._h)
             self._h = _P()
 
@@ -341,6 +366,11 @@ class Context:
         )
         return i, mun, mus
 
+    def sampler(self, chains, theta0, tune: int, seed: int = 0, target_accept: float = 0.8, max_treedepth: int = 10,
+                gibbs: bool = True, accumulate: bool = False) -> "NativeSampler":
+        """The compound step [NUTS; Gibbs sweep] for several chains in lock step, driven inside the library."""
+        return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate)
+
     # -- measurement --------------------------------------------------------------------------
     def kernel_timing(self, enable: bool):
         _check(self._lib, self._lib.abd_kernel_timing(self._h, int(enable)))
@@ -353,3 +383,56 @@ class Context:
         n = C.c_int64()
         _check(self._lib, self._lib.abd_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
+
+
+class NativeSampler:
+    """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922), one launch per lock-step leapfrog."""
+
+    def __init__(self, ctx: Context, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate):
+        self._ctx = ctx  # keeps the context alive
+        self._lib = ctx._lib
+        self._h = _P()
+        ch = _as(np.atleast_1d(chains), np.int32)
+        t0 = _as(np.atleast_2d(theta0), np.float64)
+        if t0.shape != (ch.size, N_THETA):
+            raise ValueError(f"theta0 must have shape ({ch.size}, {N_THETA})")
+        self.n = int(ch.size)
+        o = _SamplerOpts()
+        o.tune, o.seed = int(tune), int(seed) & (2**64 - 1)
+        o.target_accept, o.max_treedepth = float(target_accept), int(max_treedepth)
+        o.gibbs, o.accumulate = int(bool(gibbs)), int(bool(accumulate))
+        _check(self._lib, self._lib.abd_sampler_create(ctx._h, self.n, _ptr(ch, C.c_int32), _ptr(t0, C.c_double), C.byref(o),
+                                                       C.byref(self._h)))
+        ctx._samplers.add(self)
+
+    def run(self, n_iter: int):
+        """Advance all chains by n_iter iterations -> theta (n, n_iter, 17), stats {name: (n, n_iter)}."""
+        theta = np.empty((self.n, n_iter, N_THETA))
+        stats = np.empty((self.n, n_iter, N_STATS))
+        _check(self._lib, self._lib.abd_sampler_run(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double)))
+        return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}
+
+    def means(self, k: int):
+        """Posterior means of i, ab_n_mu, ab_s_mu of the k-th chain over the accumulated draws, and their count."""
+        G, N = self._ctx.n_gaps, self._ctx.n_inds
+        out = [np.empty((G, N)) for _ in range(3)]
+        n = C.c_int64()
+        _check(self._lib, self._lib.abd_sampler_means(self._h, int(k), *[_ptr(o, C.c_double) for o in out], C.byref(n)))
+        return out[0], out[1], out[2], n.value
+
+    def adaptation(self, k: int):
+        inv_mass = np.empty(N_THETA)
+        eps = C.c_double()
+        _check(self._lib, self._lib.abd_sampler_adaptation(self._h, int(k), _ptr(inv_mass, C.c_double), C.byref(eps)))
+        return inv_mass, eps.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.abd_sampler_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

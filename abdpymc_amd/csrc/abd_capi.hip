@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/abd_hip.h"
+#include "abd_nuts.hpp"
 
 static_assert(ABD_MAX_BATCH == ABD_MAX_BATCH_K, "header / kernel batch size mismatch");
 static_assert(ABD_MAX_GAPS == 64 * ABD_MAXT, "header / kernel gap limit mismatch");
@@ -450,9 +451,14 @@ int flush_ring(abd_ctx* c) {
 // falls back to a stream synchronise if it does not show up quickly.
 int wait_rows(abd_ctx* c, int slot, int n, double tag) {
   volatile const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
-  const int k = n - 1;  // groups complete in order on the stream: the last row's tag is the last to land
+  // every row is written by its own workgroup (row, system-scope fence, tag), in no particular order: wait for
+  // each tag.  Rows of an earlier group of the same call carry a smaller tag and count as landed once a later
+  // group's rows are there (groups complete in stream order), so only the last group's tag value is awaited.
+  const int first = ((n - 1) / ABD_MAX_BATCH) * ABD_MAX_BATCH;
+  int k = n - 1;
   for (int spin = 0; spin < 2000000; ++spin) {
-    if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] == tag) {
+    while (k >= first && rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] == tag) --k;
+    if (k < first) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       return ABD_OK;
     }
@@ -897,7 +903,8 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
     a.ch[0] = chain_par(c, chain, theta);
     const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s);
+    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s,
+                       (double*)nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1035,6 +1042,203 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   const int64_t bits = (int64_t)c->nt * c->N * 8 * (2 + n_chains) + (int64_t)n_chains * c->N;
   if (c->dense) return cells * 4 * R + bits;
   return (c->s.K + c->n.K) * (2 * R + 1) + 2 * (int64_t)(c->N + 1) * 4 + bits;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Native compound sampler: lock-step NUTS over the chains + the device Gibbs sweep (abd_hip.h)
+// ---------------------------------------------------------------------------------------------------
+struct abd_sampler {
+  abd_ctx* c = nullptr;
+  int n = 0;
+  abd_sampler_opts o{};
+  std::vector<int32_t> chains;
+  std::vector<abdnuts::AdaptiveNuts> ch;
+  int64_t it = 0;
+  double* d_sums = nullptr;  // [n][3][G*N]
+  int64_t n_accumulated = 0;
+  // scratch of one lock-step round
+  std::vector<int32_t> ids, who;
+  std::vector<double> th, lp, gr;
+};
+
+namespace {
+
+int sampler_accumulate(abd_sampler* s) {
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N;
+  const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
+  const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+  for (int k = 0; k < s->n; ++k) {
+    EvalArgs a;
+    base_args(c, a);
+    a.n_chains = 1;
+    a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
+    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, (int8_t*)nullptr,
+                       (double*)nullptr, (double*)nullptr, s->d_sums + (size_t)k * 3 * cells);
+    HIP_TRY(hipGetLastError());
+  }
+  s->n_accumulated += 1;
+  return ABD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta0, const abd_sampler_opts* opts,
+                       abd_sampler** out) {
+  if (!c || !chains || !theta0 || !opts || !out) return fail(ABD_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  int rc = check_chains(c, n, chains);
+  if (rc) return rc;
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (chains[a] == chains[b]) return fail(ABD_ERR_ARG, "chain %d listed twice", chains[a]);
+  if (opts->tune < 0) return fail(ABD_ERR_ARG, "tune=%lld is negative", (long long)opts->tune);
+  if (opts->max_treedepth < 1 || opts->max_treedepth > abdnuts::MAX_DEPTH)
+    return fail(ABD_ERR_ARG, "max_treedepth=%d outside [1, %d]", opts->max_treedepth, abdnuts::MAX_DEPTH);
+  if (!(opts->target_accept > 0.0 && opts->target_accept < 1.0))
+    return fail(ABD_ERR_ARG, "target_accept=%g outside (0, 1)", opts->target_accept);
+  abd_sampler* s = new (std::nothrow) abd_sampler();
+  if (!s) return fail(ABD_ERR_NOMEM, "out of host memory");
+  s->c = c;
+  s->n = n;
+  s->o = *opts;
+  s->chains.assign(chains, chains + n);
+  s->ch.resize((size_t)n);
+  s->ids.resize((size_t)n);
+  s->who.resize((size_t)n);
+  s->th.resize((size_t)n * ABD_N_THETA);
+  s->lp.resize((size_t)n);
+  s->gr.resize((size_t)n * ABD_N_THETA);
+  rc = abd_logp_dlogp_batch(c, n, chains, theta0, s->lp.data(), s->gr.data());
+  if (rc) {
+    delete s;
+    return rc;
+  }
+  for (int k = 0; k < n; ++k) {
+    if (!std::isfinite(s->lp[(size_t)k])) {
+      delete s;
+      return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
+    }
+    s->ch[(size_t)k].init(theta0 + (size_t)k * ABD_N_THETA, s->lp[(size_t)k], s->gr.data() + (size_t)k * ABD_N_THETA,
+                          opts->seed, (uint64_t)chains[k], opts->tune, opts->max_treedepth, opts->target_accept);
+  }
+  if (opts->accumulate) {
+    const size_t bytes = (size_t)n * 3 * c->G * c->N * sizeof(double);
+    hipError_t e = hipMalloc(&s->d_sums, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_sums, 0, bytes, c->stream);
+    if (e != hipSuccess) {
+      if (s->d_sums) (void)hipFree(s->d_sums);
+      delete s;
+      return fail(ABD_ERR_HIP, "sampler sums: %s", hipGetErrorString(e));
+    }
+  }
+  *out = s;
+  return ABD_OK;
+}
+
+void abd_sampler_destroy(abd_sampler* s) {
+  if (!s) return;
+  if (s->d_sums) {
+    (void)hipSetDevice(s->c->device);
+    (void)hipStreamSynchronize(s->c->stream);
+    (void)hipFree(s->d_sums);
+  }
+  delete s;
+}
+
+int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (n_iter < 0) return fail(ABD_ERR_ARG, "n_iter=%lld is negative", (long long)n_iter);
+  abd_ctx* c = s->c;
+  const int n = s->n;
+  std::vector<int64_t> acc((size_t)n, 0), prop((size_t)n, 0);
+  for (int64_t k = 0; k < n_iter; ++k) {
+    // ---- NUTS: all chains advance one leapfrog per launch until every tree has stopped ----
+    for (auto& a : s->ch) a.nuts.begin();
+    for (;;) {
+      int m = 0;
+      for (int j = 0; j < n; ++j) {
+        abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+        if (!nu.active) continue;
+        s->ids[(size_t)m] = s->chains[(size_t)j];
+        s->who[(size_t)m] = j;
+        std::memcpy(s->th.data() + (size_t)m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
+        ++m;
+      }
+      if (m == 0) break;
+      int rc = abd_logp_dlogp_batch(c, m, s->ids.data(), s->th.data(), s->lp.data(), s->gr.data());
+      if (rc) return rc;
+      for (int j = 0; j < m; ++j)
+        s->ch[(size_t)s->who[(size_t)j]].nuts.feed(s->lp[(size_t)j], s->gr.data() + (size_t)j * ABD_N_THETA);
+    }
+    const bool draw = s->it >= s->o.tune;
+    for (auto& a : s->ch) a.end_transition();
+    // ---- binary Gibbs-Metropolis on [i_raw, ab_s_waner], then logp and gradient at the new state ----
+    if (s->o.gibbs) {
+      for (int j = 0; j < n; ++j)
+        std::memcpy(s->th.data() + (size_t)j * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
+      int rc = abd_gibbs_sweep(c, n, s->chains.data(), s->th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)s->it,
+                               acc.data(), prop.data());
+      if (rc) return rc;
+      rc = abd_logp_dlogp_batch(c, n, s->chains.data(), s->th.data(), s->lp.data(), s->gr.data());
+      if (rc) return rc;
+      for (int j = 0; j < n; ++j) s->ch[(size_t)j].nuts.set_point(s->lp[(size_t)j], s->gr.data() + (size_t)j * ABD_N_THETA);
+    }
+    for (int j = 0; j < n; ++j) {
+      const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+      if (theta) std::memcpy(theta + ((size_t)j * n_iter + k) * ABD_N_THETA, nu.q, sizeof(double) * ABD_N_THETA);
+      if (stats) {
+        double* r = stats + ((size_t)j * n_iter + k) * ABD_N_STATS;
+        r[ABD_STAT_LP] = nu.lp;
+        r[ABD_STAT_TREE_DEPTH] = nu.stats.tree_depth;
+        r[ABD_STAT_N_STEPS] = nu.stats.n_steps;
+        r[ABD_STAT_MEAN_TREE_ACCEPT] = nu.stats.mean_tree_accept;
+        r[ABD_STAT_STEP_SIZE] = nu.stats.step_size;
+        r[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
+        r[ABD_STAT_ENERGY] = nu.stats.energy;
+        r[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
+        r[ABD_STAT_GIBBS_ACCEPTED] = (double)acc[(size_t)j];
+        r[ABD_STAT_GIBBS_PROPOSED] = (double)prop[(size_t)j];
+      }
+    }
+    if (draw && s->d_sums) {
+      int rc = sampler_accumulate(s);
+      if (rc) return rc;
+    }
+    s->it += 1;
+  }
+  return ABD_OK;
+}
+
+int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* mu_n_mean, double* mu_s_mean, int64_t* n_draws) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
+  if (!s->d_sums) return fail(ABD_ERR_STATE, "the sampler was created without accumulate");
+  abd_ctx* c = s->c;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t cells = (size_t)c->G * c->N;
+  double* outs[3] = {i_mean, mu_n_mean, mu_s_mean};
+  const double inv = s->n_accumulated ? 1.0 / (double)s->n_accumulated : 0.0;
+  for (int v = 0; v < 3; ++v) {
+    if (!outs[v]) continue;
+    HIP_TRY(hipMemcpy(outs[v], s->d_sums + ((size_t)k * 3 + v) * cells, cells * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < cells; ++e) outs[v][e] *= inv;
+  }
+  if (n_draws) *n_draws = s->n_accumulated;
+  return ABD_OK;
+}
+
+int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
+  if (inv_mass) std::memcpy(inv_mass, s->ch[(size_t)k].nuts.inv_mass, sizeof(double) * ABD_N_THETA);
+  if (step_size) *step_size = s->ch[(size_t)k].nuts.eps;
+  return ABD_OK;
 }
 
 }  // extern "C"

@@ -615,10 +615,12 @@ __global__ void abd_flip_kernel(uint64_t* rw, int8_t* waner, int G, int N, int64
   }
 }
 
-// Deterministics "i", "ab_n_mu", "ab_s_mu" for one chain, written (G, N) gap-major as PyMC records them.
+// Deterministics "i", "ab_n_mu", "ab_s_mu" for one chain, written (G, N) gap-major as PyMC records them;
+// with `sums` ([3][G*N]: i, ab_n_mu, ab_s_mu) they are also added to running sums (posterior means on device).
 __global__ __launch_bounds__(ABD_BLOCK) void abd_deterministics_kernel(const EvalArgs a, int8_t* __restrict__ out_i,
                                                                        double* __restrict__ out_mun,
-                                                                       double* __restrict__ out_mus) {
+                                                                       double* __restrict__ out_mus,
+                                                                       double* __restrict__ sums) {
   extern __shared__ __align__(16) unsigned char smem[];
   double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   const int G = a.G, N = a.N, nt = a.nt, tstride = G + 1;
@@ -650,9 +652,18 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_deterministics_kernel(const Eva
       if (g < G) {
         const Resp rs = responses(g, t + 1, I, V, tabs, ts);
         const int64_t o = (int64_t)g * N + j;
-        if (out_i) out_i[o] = (int8_t)((I[t] >> lane) & 1ull);
-        if (out_mun) out_mun[o] = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-        if (out_mus) out_mus[o] = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
+        const int bit = (int)((I[t] >> lane) & 1ull);
+        const double mun = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
+        const double mus = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
+        if (out_i) out_i[o] = (int8_t)bit;
+        if (out_mun) out_mun[o] = mun;
+        if (out_mus) out_mus[o] = mus;
+        if (sums) {
+          const int64_t cells = (int64_t)G * N;
+          sums[o] += (double)bit;
+          sums[cells + o] += mun;
+          sums[2 * cells + o] += mus;
+        }
       }
     }
   }

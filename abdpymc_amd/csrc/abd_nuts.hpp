@@ -1,0 +1,378 @@
+// abd_nuts.hpp -- host side of the compound step: a No-U-Turn transition written as a state machine.
+//
+// The reference hands the model to pm.sample (abd.py:921-922), which assigns NUTS to the 17 continuous
+// value variables.  PyMC's NUTS is a recursive tree builder that calls logp_dlogp once per leapfrog; here
+// the same transition is unrolled into "give me the next point to evaluate" / "here is logp and gradient",
+// so that a driver can collect the pending points of many chains and evaluate them in ONE device launch.
+//
+// Algorithm: multinomial NUTS with a diagonal metric (Betancourt 2017; the variant PyMC and Stan run):
+//  * tree doubling in a random direction, the new half built leaf by leaf;
+//  * every leaf z gets weight exp(H0 - H(z)); the new half's candidate is drawn leaf by leaf with
+//    probability w / (sum of w so far) (uniform-multinomial inside a half), and replaces the tree's candidate
+//    with probability min(1, W_new / W_old) (biased progressive sampling across halves);
+//  * the generalised U-turn test  rho . M^-1 p_- > 0  and  rho . M^-1 p_+ > 0  on every balanced sub-tree of
+//    the new half (checked without recursion from O(depth) checkpoints: a leaf with an even index stores
+//    (p, running rho); a leaf with an odd index closes one sub-tree per trailing 1-bit of its index) and on
+//    the whole tree after each doubling;
+//  * a leaf whose energy error exceeds 1000 marks the transition divergent and ends it.
+// Step size: dual averaging (Hoffman & Gelman 2014, eq. 6; PyMC's constants gamma 0.05, t0 10, kappa 0.75,
+// initial step 0.25 / d^(1/4), mu = log(10 * initial)).  Metric: running weighted variance of the tuning
+// draws with a foreground and a background window of 101 draws (PyMC's QuadPotentialDiagAdapt; initial
+// variance 1 with weight 10).  PyMC itself is not importable offline: these constants are restated from its
+// documentation and the tests check the sampler on closed-form targets, not against PyMC draws.
+//
+// No HIP in this file: tests/native compiles it with g++ against an analytic target.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+namespace abdnuts {
+
+constexpr int D = 17;        // continuous value variables
+constexpr int MAX_DEPTH = 16;  // hard cap on the tree depth the checkpoints are sized for
+
+// xoshiro256++ (Blackman & Vigna), seeded through splitmix64: one independent stream per chain
+struct Rng {
+  uint64_t s[4];
+  bool have_spare = false;
+  double spare = 0.0;
+  static uint64_t splitmix(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  void seed(uint64_t seed, uint64_t stream) {
+    uint64_t x = seed ^ (0xD1B54A32D192ED03ull * (stream + 1));
+    for (int k = 0; k < 4; ++k) s[k] = splitmix(x);
+    have_spare = false;
+  }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t r = rotl(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return r;
+  }
+  double uniform() { return (double)(next() >> 11) * 0x1.0p-53; }  // [0, 1)
+  double normal() {                                                  // Box-Muller, both values used
+    if (have_spare) {
+      have_spare = false;
+      return spare;
+    }
+    const double u = 1.0 - uniform();  // (0, 1]
+    const double v = uniform();
+    const double r = std::sqrt(-2.0 * std::log(u));
+    const double a = 6.283185307179586476925 * v;
+    spare = r * std::sin(a);
+    have_spare = true;
+    return r * std::cos(a);
+  }
+};
+
+inline double log_add_exp(double a, double b) {
+  if (a == -std::numeric_limits<double>::infinity()) return b;
+  if (b == -std::numeric_limits<double>::infinity()) return a;
+  const double m = a > b ? a : b;
+  return m + std::log(std::exp(a - m) + std::exp(b - m));
+}
+
+struct DualAveraging {
+  double mu = 0, target = 0.8, gamma = 0.05, t0 = 10.0, kappa = 0.75;
+  double h_bar = 0, log_eps_bar = 0;
+  int64_t m = 0;
+  void init(double eps0, double target_accept) {
+    mu = std::log(10.0 * eps0);
+    target = target_accept;
+    h_bar = 0;
+    log_eps_bar = 0;
+    m = 0;
+  }
+  double update(double accept_stat) {  // -> step size for the next tuning transition
+    m += 1;
+    const double w = 1.0 / ((double)m + t0);
+    h_bar = (1.0 - w) * h_bar + w * (target - accept_stat);
+    const double log_eps = mu - std::sqrt((double)m) / gamma * h_bar;
+    const double eta = std::pow((double)m, -kappa);
+    log_eps_bar = eta * log_eps + (1.0 - eta) * log_eps_bar;
+    return std::exp(log_eps);
+  }
+  double final_eps() const { return std::exp(log_eps_bar); }
+};
+
+// running mean / sum of squared deviations (Welford) with an optional prior weight
+struct WeightedVariance {
+  double n = 0;
+  double mean[D];
+  double m2[D];
+  void reset() {
+    n = 0;
+    for (int k = 0; k < D; ++k) mean[k] = m2[k] = 0.0;
+  }
+  void prior(const double* mean0, double var0, double weight) {
+    n = weight;
+    for (int k = 0; k < D; ++k) {
+      mean[k] = mean0[k];
+      m2[k] = var0 * weight;
+    }
+  }
+  void add(const double* x) {
+    n += 1.0;
+    for (int k = 0; k < D; ++k) {
+      const double d = x[k] - mean[k];
+      mean[k] += d / n;
+      m2[k] += d * (x[k] - mean[k]);
+    }
+  }
+  void variance(double* out) const {
+    for (int k = 0; k < D; ++k) out[k] = m2[k] / n;
+  }
+};
+
+struct MassAdapt {
+  WeightedVariance fg, bg;
+  int64_t n_seen = 0;
+  int window = 101;
+  void init(const double* q0) {
+    fg.prior(q0, 1.0, 10.0);
+    bg.reset();
+    n_seen = 0;
+  }
+  // one tuning draw; writes the new diagonal of M^-1
+  void update(const double* q, double* inv_mass) {
+    fg.add(q);
+    bg.add(q);
+    fg.variance(inv_mass);
+    for (int k = 0; k < D; ++k)
+      if (!(inv_mass[k] > 1e-12) || !std::isfinite(inv_mass[k])) inv_mass[k] = 1e-12;
+    n_seen += 1;
+    if (n_seen % window == 0) {
+      fg = bg;
+      bg.reset();
+    }
+  }
+};
+
+struct Stats {
+  double lp = 0, energy = 0, step_size = 0, mean_tree_accept = 0, max_energy_error = 0;
+  int tree_depth = 0, n_steps = 0;
+  bool diverging = false, reached_max_depth = false;
+};
+
+struct Phase {
+  double q[D], p[D], g[D];
+};
+
+struct Nuts {
+  // ---- persistent state of the chain ----
+  double q[D], g[D], lp = 0;
+  double inv_mass[D];
+  double eps = 0.1;
+  int max_depth = 10;
+  Rng rng;
+  Stats stats;
+
+  // ---- one transition ----
+  bool active = false;
+  double h0 = 0;
+  Phase left, right, cur;
+  double rho[D], log_w = 0;
+  double prop_q[D], prop_g[D], prop_lp = 0;
+  int depth = 0, dir = 1, n_leaf = 0, n_target = 1;
+  double sub_rho[D], sub_log_w = 0;
+  double sub_q[D], sub_g[D], sub_lp = 0;
+  double p_ckpt[MAX_DEPTH][D], rho_ckpt[MAX_DEPTH][D];
+  double sum_alpha = 0, max_err = 0;
+  int n_alpha = 0;
+  double req_q[D], p_half[D];
+
+  void init(const double* q0, double lp0, const double* g0, uint64_t seed, uint64_t stream) {
+    std::memcpy(q, q0, sizeof(q));
+    std::memcpy(g, g0, sizeof(g));
+    lp = lp0;
+    for (int k = 0; k < D; ++k) inv_mass[k] = 1.0;
+    rng.seed(seed, stream);
+    active = false;
+  }
+  void set_point(double lp0, const double* g0) {  // the discrete state changed under the chain
+    lp = lp0;
+    std::memcpy(g, g0, sizeof(g));
+  }
+
+  double kinetic(const double* p) const {
+    double k = 0;
+    for (int d = 0; d < D; ++d) k += inv_mass[d] * p[d] * p[d];
+    return 0.5 * k;
+  }
+  double dot_sharp(const double* r, const double* p) const {  // r . M^-1 p
+    double s = 0;
+    for (int d = 0; d < D; ++d) s += r[d] * inv_mass[d] * p[d];
+    return s;
+  }
+
+  void begin() {
+    if (max_depth > MAX_DEPTH) max_depth = MAX_DEPTH;
+    double p0[D];
+    for (int d = 0; d < D; ++d) p0[d] = rng.normal() / std::sqrt(inv_mass[d]);
+    h0 = -lp + kinetic(p0);
+    std::memcpy(left.q, q, sizeof(q));
+    std::memcpy(left.p, p0, sizeof(p0));
+    std::memcpy(left.g, g, sizeof(g));
+    right = left;
+    std::memcpy(rho, p0, sizeof(p0));
+    log_w = 0.0;
+    std::memcpy(prop_q, q, sizeof(q));
+    std::memcpy(prop_g, g, sizeof(g));
+    prop_lp = lp;
+    depth = 0;
+    sum_alpha = 0;
+    n_alpha = 0;
+    max_err = 0;
+    stats = Stats();
+    stats.step_size = eps;
+    active = true;
+    start_half();
+  }
+
+  // the point whose logp and gradient the transition needs next (valid while active)
+  const double* request() const { return req_q; }
+
+  void feed(double lp1, const double* g1) {
+    const bool finite = std::isfinite(lp1);
+    const double ve = dir * eps;
+    std::memcpy(cur.q, req_q, sizeof(req_q));
+    for (int d = 0; d < D; ++d) {
+      cur.g[d] = finite ? g1[d] : 0.0;
+      cur.p[d] = p_half[d] + 0.5 * ve * cur.g[d];
+    }
+    double dh = finite ? (-lp1 + kinetic(cur.p)) - h0 : std::numeric_limits<double>::infinity();
+    if (std::isnan(dh)) dh = std::numeric_limits<double>::infinity();
+    sum_alpha += dh <= 0 ? 1.0 : std::exp(-dh);
+    n_alpha += 1;
+    if (std::fabs(dh) > std::fabs(max_err)) max_err = dh;
+    if (dh > 1000.0) {
+      stats.diverging = true;
+      finish();
+      return;
+    }
+    const double w = -dh;
+    sub_log_w = log_add_exp(sub_log_w, w);
+    if (rng.uniform() < std::exp(w - sub_log_w)) {
+      std::memcpy(sub_q, cur.q, sizeof(sub_q));
+      std::memcpy(sub_g, cur.g, sizeof(sub_g));
+      sub_lp = lp1;
+    }
+    for (int d = 0; d < D; ++d) sub_rho[d] += cur.p[d];
+    bool turning = false;
+    const unsigned n = (unsigned)n_leaf;
+    const int idx_max = __builtin_popcount(n >> 1);
+    if ((n & 1u) == 0) {
+      std::memcpy(p_ckpt[idx_max], cur.p, sizeof(cur.p));
+      std::memcpy(rho_ckpt[idx_max], sub_rho, sizeof(sub_rho));
+    } else {
+      const int closing = __builtin_ctz(~n);  // trailing 1-bits: sub-trees that end at this leaf
+      for (int k = idx_max; k > idx_max - closing && !turning; --k) {
+        double span[D];
+        for (int d = 0; d < D; ++d) span[d] = sub_rho[d] - rho_ckpt[k][d] + p_ckpt[k][d];
+        turning = !(dot_sharp(span, p_ckpt[k]) > 0.0 && dot_sharp(span, cur.p) > 0.0);
+      }
+    }
+    n_leaf += 1;
+    if (turning) {  // the new half is discarded
+      depth += 1;
+      finish();
+      return;
+    }
+    if (n_leaf < n_target) {
+      stage_leapfrog();
+      return;
+    }
+    // the half is complete: merge it into the tree
+    if (sub_log_w > log_w || rng.uniform() < std::exp(sub_log_w - log_w)) {
+      std::memcpy(prop_q, sub_q, sizeof(sub_q));
+      std::memcpy(prop_g, sub_g, sizeof(sub_g));
+      prop_lp = sub_lp;
+    }
+    log_w = log_add_exp(log_w, sub_log_w);
+    for (int d = 0; d < D; ++d) rho[d] += sub_rho[d];
+    (dir < 0 ? left : right) = cur;
+    depth += 1;
+    const bool whole_turning = !(dot_sharp(rho, left.p) > 0.0 && dot_sharp(rho, right.p) > 0.0);
+    if (whole_turning) {
+      finish();
+    } else if (depth >= max_depth) {
+      stats.reached_max_depth = true;
+      finish();
+    } else {
+      start_half();
+    }
+  }
+
+ private:
+  void start_half() {
+    dir = rng.uniform() < 0.5 ? -1 : 1;
+    cur = dir < 0 ? left : right;
+    n_leaf = 0;
+    n_target = 1 << depth;
+    for (int d = 0; d < D; ++d) sub_rho[d] = 0.0;
+    sub_log_w = -std::numeric_limits<double>::infinity();
+    stage_leapfrog();
+  }
+  void stage_leapfrog() {  // half kick + drift; the second half kick waits for the gradient
+    const double ve = dir * eps;
+    for (int d = 0; d < D; ++d) {
+      p_half[d] = cur.p[d] + 0.5 * ve * cur.g[d];
+      req_q[d] = cur.q[d] + ve * inv_mass[d] * p_half[d];
+    }
+  }
+  void finish() {
+    std::memcpy(q, prop_q, sizeof(q));
+    std::memcpy(g, prop_g, sizeof(g));
+    lp = prop_lp;
+    stats.lp = lp;
+    stats.tree_depth = depth;
+    stats.n_steps = n_alpha;
+    stats.mean_tree_accept = n_alpha ? sum_alpha / n_alpha : 0.0;
+    stats.max_energy_error = max_err;
+    stats.energy = h0;
+    active = false;
+  }
+};
+
+// NUTS + its two adaptations for one chain
+struct AdaptiveNuts {
+  Nuts nuts;
+  DualAveraging da;
+  MassAdapt mass;
+  int64_t tune = 0, it = 0;
+  void init(const double* q0, double lp0, const double* g0, uint64_t seed, uint64_t stream, int64_t n_tune,
+            int max_depth, double target_accept) {
+    nuts.init(q0, lp0, g0, seed, stream);
+    nuts.max_depth = max_depth;
+    nuts.eps = 0.25 / std::pow((double)D, 0.25);
+    da.init(nuts.eps, target_accept);
+    mass.init(q0);
+    tune = n_tune;
+    it = 0;
+  }
+  bool tuning() const { return it < tune; }
+  // call when the transition of iteration `it` has finished
+  void end_transition() {
+    if (it < tune) {
+      nuts.eps = da.update(nuts.stats.mean_tree_accept);
+      // PyMC stops adapting the metric for the last stretch of tuning so the step size can settle
+      if (it < tune - tune / 10 - 1) mass.update(nuts.q, nuts.inv_mass);
+      if (it == tune - 1) nuts.eps = da.final_eps();
+    }
+    it += 1;
+  }
+};
+
+}  // namespace abdnuts

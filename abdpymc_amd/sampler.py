@@ -277,11 +277,92 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
     return res
 
 
+def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
+                  record_discrete: bool = True, progress: Optional[Callable[[int, int, int], None]] = None,
+                  target_accept: float = 0.8, max_treedepth: int = 10, chunk: int = 50) -> Dict[str, np.ndarray]:
+    """
+    All chains in lock step inside the library (``abd_sampler_*``): one launch per leapfrog for all chains, one
+    launch per Gibbs sweep for all chains.  Posterior means of the three Deterministics are accumulated on the
+    device and returned as ``mean_i``, ``mean_ab_n_mu``, ``mean_ab_s_mu``; per-draw copies only when asked for.
+    """
+    from .model import THETA_NAMES, constrain
+
+    ctx = model.ctx
+    G, N = model.n_gaps, model.n_inds
+    pt = model.initial_point()
+    q0 = np.empty((chains, len(THETA_NAMES)))
+    for c in range(chains):
+        rng = np.random.default_rng([seed, c])
+        ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
+        q0[c] = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # jitter as pm.sample does
+    smp = ctx.sampler(np.arange(chains), q0, tune=tune, seed=seed, target_accept=target_accept,
+                      max_treedepth=max_treedepth, gibbs=True, accumulate=True)
+    n_grad = chains  # the evaluation at the starting points
+    done = 0
+
+    def advance(n):
+        nonlocal done, n_grad
+        th, st = smp.run(n)
+        n_grad += int(st["n_steps"].sum()) + n * chains  # leapfrogs + the re-evaluation after each sweep
+        done += n
+        if progress is not None:
+            for c in range(chains):
+                progress(c, done, tune + draws)
+        return th, st
+
+    left = tune
+    while left > 0:
+        advance(min(chunk, left))
+        left -= min(chunk, left)
+    per_draw = record_deterministics or record_discrete
+    thetas, stats = [], []
+    out_i_raw = np.empty((chains, draws, G, N), dtype=np.int8) if record_discrete else None
+    out_w = np.empty((chains, draws, N), dtype=np.int8) if record_discrete else None
+    det = None
+    if record_deterministics:
+        det = dict(i=np.empty((chains, draws, G, N), dtype=np.int8), ab_n_mu=np.empty((chains, draws, G, N)),
+                   ab_s_mu=np.empty((chains, draws, G, N)))
+    k = 0
+    while k < draws:
+        n = 1 if per_draw else min(chunk, draws - k)
+        th, st = advance(n)
+        thetas.append(th)
+        stats.append(st)
+        if per_draw:
+            for c in range(chains):
+                if record_discrete:
+                    out_i_raw[c, k], out_w[c, k] = ctx.get_discrete(c)
+                if det is not None:
+                    det["i"][c, k], det["ab_n_mu"][c, k], det["ab_s_mu"][c, k] = ctx.deterministics(c, th[c, 0])
+        k += n
+    out_q = np.concatenate(thetas, axis=1) if thetas else np.empty((chains, 0, len(THETA_NAMES)))
+    res = {name: out_q[:, :, j].copy() for j, name in enumerate(THETA_NAMES)}
+    res.update(constrain(out_q))
+    if record_discrete:
+        res["i_raw"], res["ab_s_waner"] = out_i_raw, out_w
+    if det is not None:
+        res.update(det)
+    if draws:
+        means = [smp.means(c) for c in range(chains)]
+        for j, name in enumerate(("mean_i", "mean_ab_n_mu", "mean_ab_s_mu")):
+            res[name] = np.stack([m[j] for m in means])
+        cat = {name: np.concatenate([s[name] for s in stats], axis=1) for name in stats[0]}
+        for name in ("lp", "tree_depth", "mean_tree_accept", "step_size", "n_steps", "diverging", "energy"):
+            res[f"stat_{name}"] = cat[name]
+        res["stat_gibbs_accept"] = cat["gibbs_accepted"] / np.maximum(cat["gibbs_proposed"], 1)
+    res["n_grad_evals"] = np.full(chains, n_grad // chains)
+    smp.close()
+    return res
+
+
 def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
-           progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True) -> Dict[str, np.ndarray]:
+           progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True,
+           native: bool = True, record_discrete: bool = True) -> Dict[str, np.ndarray]:
     """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
     if chains > model.n_chains:
         raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
+    if native and device_gibbs and hasattr(model.ctx, "sampler"):
+        return sample_native(model, tune, draws, chains, seed, record_deterministics, record_discrete, progress)
     per_chain = []
     for c in range(chains):
         cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None

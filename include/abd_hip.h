@@ -142,6 +142,54 @@ int abd_fetch_many(abd_ctx* ctx, int32_t n_slots, const int32_t* slots, double* 
 int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t* i, double* ab_n_mu,
                        double* ab_s_mu);
 
+/* ---------------------------------------------------------------------------------------------------
+ * The compound step pm.sample assigns to this model (reference call site abd.py:921-922), run natively
+ * for several chains in lock step: NUTS on the 17 continuous variables -- every chain's pending leapfrog
+ * point is evaluated in ONE abd_logp_dlogp_batch launch -- then one abd_gibbs_sweep over all chains, then
+ * one batched re-evaluation at the new discrete state.  This removes the host-language cost per leapfrog
+ * (PyMC: Python).  Step size: dual averaging to `target_accept`; metric: diagonal,
+ * windowed running variance of the tuning draws (abdpymc_amd/csrc/abd_nuts.hpp).
+ * Iterations [0, tune) adapt; later ones are draws.  Randomness: one xoshiro256++ stream per chain keyed by
+ * (seed, chain slot) for NUTS; Philox keyed by (seed, iteration) for the sweep. */
+typedef struct abd_sampler abd_sampler;
+
+typedef struct abd_sampler_opts {
+  int64_t tune;           /* iterations that adapt step size and metric */
+  uint64_t seed;
+  double target_accept;   /* 0.8 as pm.sample */
+  int32_t max_treedepth;  /* 10 as pm.sample; at most 16 */
+  int32_t gibbs;          /* 1: sweep [i_raw, ab_s_waner] after every NUTS transition; 0: continuous part only */
+  int32_t accumulate;     /* 1: add i, ab_n_mu, ab_s_mu of every draw (iteration >= tune) into device sums */
+  int32_t reserved;
+} abd_sampler_opts;
+
+#define ABD_N_STATS 10
+/* columns of the per-iteration statistics row */
+#define ABD_STAT_LP 0                /* joint logp after the whole compound step */
+#define ABD_STAT_TREE_DEPTH 1
+#define ABD_STAT_N_STEPS 2           /* leapfrogs = logp_dlogp evaluations of the transition */
+#define ABD_STAT_MEAN_TREE_ACCEPT 3
+#define ABD_STAT_STEP_SIZE 4
+#define ABD_STAT_DIVERGING 5
+#define ABD_STAT_ENERGY 6
+#define ABD_STAT_MAX_ENERGY_ERROR 7
+#define ABD_STAT_GIBBS_ACCEPTED 8
+#define ABD_STAT_GIBBS_PROPOSED 9
+
+/* chains[k] must hold a discrete state (abd_set_discrete); theta0 is n x 17, the starting points. */
+int abd_sampler_create(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta0,
+                       const abd_sampler_opts* opts, abd_sampler** out);
+void abd_sampler_destroy(abd_sampler* s);
+/* Advance every chain by n_iter iterations.  theta: n x n_iter x 17, stats: n x n_iter x ABD_N_STATS
+ * (either may be NULL).  The discrete state after the call is read with abd_get_discrete. */
+int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats);
+/* Posterior means of the Deterministics of chain k (0 <= k < n) over the draws accumulated so far, each
+ * (G, N); any pointer may be NULL.  *n_draws receives the number of accumulated draws. */
+int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu_mean, double* ab_s_mu_mean,
+                      int64_t* n_draws);
+/* Current diagonal of M^-1 (17) and step size of chain k. */
+int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size);
+
 /* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
  * events on the context's stream; abd_kernel_time returns the accumulated kernel time and launch count
  * since the last reset (synchronises the stream). */

@@ -265,3 +265,22 @@ def test_stream_ordered_results_equal_synchronous_bitwise():
     np.testing.assert_array_equal(lp_b[0], lp_a[3])
     np.testing.assert_array_equal(lp_b[1], lp_a[4])
     assert abs(lp_mid[1] - lp_a[5][1]) <= 1e-12 * abs(lp_mid[1])  # 2-chain launch: other shape, equal to rounding
+
+
+def test_synchronous_batch_never_returns_a_stale_row():
+    """Each chain's 16 sums are written by their own workgroup in no particular order; the host must wait for
+    every row's completion tag, not only the last row's (regression: row 0 could be read one call late)."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(64, 12, seed=3))
+    ctx = _ctx(coh, (), n_chains=16)
+    for c in range(16):
+        _, i_raw, w = _state(coh, 300 + c)
+        ctx.set_discrete(c, i_raw, w)
+    rng = np.random.default_rng(4)
+    thetas = synthetic.theta_init(12) + 0.3 * rng.standard_normal((2, 16, 17))
+    ids = np.arange(16)
+    want = [ctx.logp_dlogp_batch(ids, thetas[k]) for k in range(2)]
+    want = [ctx.logp_dlogp_batch(ids, thetas[k]) for k in range(2)]  # second pass: every row has been overwritten
+    for it in range(6000):
+        k = it & 1
+        lp, g = ctx.logp_dlogp_batch(ids, thetas[k])
+        assert np.array_equal(lp, want[k][0]) and np.array_equal(g, want[k][1]), it

@@ -1,0 +1,214 @@
+"""
+The native compound sampler (abd_sampler_*: lock-step NUTS over the chains + device Gibbs sweep) on the GPU.
+
+NUTS draws cannot be compared with PyMC's (not importable offline; parity of the *sampler* is statistical,
+parity of every logp / gradient / sweep it consumes is tested elsewhere).  What is pinned here:
+ * bookkeeping: the recorded lp is the joint logp of the recorded theta at the resident discrete state;
+   the device-side running means equal the mean of the per-draw Deterministics; the sweep inside the
+   sampler is the same sweep abd_gibbs_sweep does (bit-exact state);
+ * reproducibility for a seed; continuous-only mode leaves the discrete state alone;
+ * statistics: with the discrete state frozen, the native sampler and an independent host NUTS agree on the
+   posterior mean and spread of all 17 variables.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from abdpymc_amd import synthetic
+from abdpymc_amd.data import TiterData
+from oracle import abd_oracle as O
+from tests.helpers import oracle_cohort_from_synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def test_td(golden_dir):
+    return TiterData.from_disk(os.path.join(golden_dir, "test_cohort"))
+
+
+def _start(m, chains, seed=0):
+    pt = m.initial_point()
+    q0 = np.empty((chains, 17))
+    for c in range(chains):
+        rng = np.random.default_rng([seed, c])
+        m.ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
+        q0[c] = m.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=17)
+    return q0
+
+
+def test_bookkeeping_means_and_reproducibility(test_td):
+    from abdpymc_amd.model import model
+
+    m = model(test_td, splits=(14, 20), n_chains=3)
+    ctx = m.ctx
+    q0 = _start(m, 3)
+    smp = ctx.sampler([0, 1, 2], q0, tune=40, seed=7, accumulate=True)
+    th_t, st_t = smp.run(40)
+    assert np.all(np.isfinite(st_t["lp"])) and st_t["tree_depth"].max() <= 10
+    np.testing.assert_allclose(st_t["step_size"][:, 0], 0.25 / 17 ** 0.25, rtol=1e-14)  # PyMC's initial step
+    assert len(np.unique(st_t["step_size"][0])) > 10  # and dual averaging moves it
+    sums = [np.zeros((3,) + (test_td.n_gaps, test_td.n_inds)) for _ in range(3)]
+    thetas = []
+    for k in range(12):
+        th, st = smp.run(1)
+        thetas.append(th[:, 0])
+        for c in range(3):
+            # lp of the iteration = joint logp of its theta at the discrete state it left behind
+            lp, _ = ctx.logp_dlogp(c, th[c, 0])
+            assert abs(lp - st["lp"][c, 0]) <= 1e-11 * abs(lp)
+            d_i, d_n, d_s = ctx.deterministics(c, th[c, 0])
+            sums[0][c] += d_i
+            sums[1][c] += d_n
+            sums[2][c] += d_s
+        assert st["gibbs_proposed"].min() > 0.6 * (26 * 10 + 10)  # transit_p = 0.8 of G*N + N dims
+        assert np.all(st["step_size"] == st["step_size"][:, :1])
+    for c in range(3):
+        mi, mn, ms, n = smp.means(c)
+        assert n == 12
+        np.testing.assert_allclose(mi, sums[0][c] / 12, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(mn, sums[1][c] / 12, rtol=1e-13)
+        np.testing.assert_allclose(ms, sums[2][c] / 12, rtol=1e-13)
+    inv_mass, eps = smp.adaptation(1)
+    assert inv_mass.shape == (17,) and np.all(inv_mass > 0) and eps == st["step_size"][1, 0]
+    state = [ctx.get_discrete(c) for c in range(3)]
+    smp.close()
+
+    # same seed, same starting point: same draws and the same discrete state, bit for bit
+    q0 = _start(m, 3)
+    smp2 = ctx.sampler([0, 1, 2], q0, tune=40, seed=7, accumulate=False)
+    th2, _ = smp2.run(52)
+    np.testing.assert_array_equal(th2[:, :40], th_t)
+    np.testing.assert_array_equal(th2[:, 40:], np.stack(thetas, axis=1))
+    for c in range(3):
+        i2, w2 = ctx.get_discrete(c)
+        np.testing.assert_array_equal(i2, state[c][0])
+        np.testing.assert_array_equal(w2, state[c][1])
+    with pytest.raises(Exception):
+        smp2.means(0)  # created without accumulate
+    smp2.close()
+    # another seed: other draws
+    q0 = _start(m, 3)
+    smp3 = ctx.sampler([0, 1, 2], q0, tune=40, seed=8)
+    th3, _ = smp3.run(5)
+    assert not np.array_equal(th3, th_t[:, :5])
+    m.close()
+
+
+def test_sweep_inside_the_sampler_is_abd_gibbs_sweep(test_td):
+    from abdpymc_amd.model import model
+
+    m = model(test_td, n_chains=2)
+    ctx = m.ctx
+    q0 = _start(m, 2)
+    smp = ctx.sampler([0, 1], q0, tune=5, seed=3)
+    th, st = smp.run(1)
+    after = [ctx.get_discrete(c) for c in range(2)]
+    # replay: same starting state, the sweep of iteration 0 at the theta the NUTS transition ended on
+    _start(m, 2)
+    acc, prop = ctx.gibbs_sweep([0, 1], th[:, 0], seed=(3 << 20) ^ 0x5EED, sweep=0)
+    for c in range(2):
+        i2, w2 = ctx.get_discrete(c)
+        np.testing.assert_array_equal(i2, after[c][0])
+        np.testing.assert_array_equal(w2, after[c][1])
+    np.testing.assert_array_equal(acc, st["gibbs_accepted"][:, 0].astype(np.int64))
+    np.testing.assert_array_equal(prop, st["gibbs_proposed"][:, 0].astype(np.int64))
+    m.close()
+
+
+def test_argument_errors(test_td):
+    from abdpymc_amd.model import model
+
+    m = model(test_td, n_chains=2)
+    q0 = _start(m, 2)
+    with pytest.raises(ValueError):
+        m.ctx.sampler([0, 0], q0, tune=5)
+    with pytest.raises(ValueError):
+        m.ctx.sampler([0, 1], q0, tune=5, max_treedepth=40)
+    with pytest.raises(ValueError):
+        m.ctx.sampler([0, 1], q0, tune=5, target_accept=1.5)
+    with pytest.raises(ValueError):
+        m.ctx.sampler([0, 1], q0[:1], tune=5)
+    bad = q0.copy()
+    bad[1, 13] = 800.0  # sigma = e^800: logp is not finite
+    with pytest.raises(ValueError):
+        m.ctx.sampler([0, 1], bad, tune=5)
+    m.close()
+
+
+def test_frozen_discrete_state_matches_host_nuts():
+    """Continuous part only (gibbs = 0) against the independent host NUTS of abdpymc_amd.sampler (slice variant)."""
+    from abdpymc_amd.model import model
+    from abdpymc_amd.sampler import DualAveraging, Nuts
+
+    sc = synthetic.make_cohort(300, 40, seed=5)
+    td = TiterData.from_arrays(40, 300, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos)
+    m = model(td, n_chains=4)
+    ctx = m.ctx
+    rng = np.random.default_rng(2)
+    i_raw = (rng.random((40, 300)) < 1 / 40).astype(np.int8)
+    w = (rng.random(300) < 0.5).astype(np.int8)
+    q_init = synthetic.theta_init(40)
+    for c in range(4):
+        ctx.set_discrete(c, i_raw, w)
+    q0 = q_init[None, :] + 0.05 * rng.uniform(-1, 1, size=(4, 17))
+    smp = ctx.sampler([0, 1, 2, 3], q0, tune=500, seed=11, gibbs=False)
+    smp.run(500)
+    th, st = smp.run(500)
+    i_after, w_after = ctx.get_discrete(2)
+    np.testing.assert_array_equal(i_after, i_raw)
+    np.testing.assert_array_equal(w_after, w)
+    assert st["diverging"].sum() <= 5
+    assert 0.6 < st["mean_tree_accept"].mean() < 0.95
+    native = th.reshape(-1, 17)
+
+    # host NUTS, one chain, same target
+    def fn(x):
+        return ctx.logp_dlogp(0, x)
+
+    nuts = Nuts(fn, 17, np.random.default_rng(3))
+    q = q0[0].copy()
+    lp, g = fn(q)
+    nuts.eps = nuts.find_reasonable_eps(q, lp, g)
+    nuts.da = DualAveraging(nuts.eps)
+    nuts.inv_mass = smp.adaptation(0)[0]  # the adapted metric; the host class adapts only the step size here
+    host = []
+    for it in range(1300):
+        q, lp, g, _ = nuts.step(q, lp, g, adapt=it < 300)
+        if it == 299:
+            nuts.eps = nuts.da.final()
+        if it >= 300:
+            host.append(q.copy())
+    host = np.asarray(host)
+    sd = native.std(0)
+    # means agree within 6 standard errors at a conservative effective sample size of n/5 for each run
+    se = sd * np.sqrt(5.0 / native.shape[0] + 5.0 / host.shape[0])
+    z = (native.mean(0) - host.mean(0)) / se
+    assert np.abs(z).max() < 6, z
+    np.testing.assert_allclose(host.std(0), sd, rtol=0.3)
+    # chains agree with each other (split R-hat-like check on the native draws)
+    per_chain = th.mean(1)
+    assert np.all(np.abs(per_chain - native.mean(0)) < 6 * sd / np.sqrt(500 / 5)), (per_chain - native.mean(0)) / sd
+    m.close()
+
+
+def test_sample_entry_point_native_and_python_paths(test_td):
+    from abdpymc_amd.model import model
+    from abdpymc_amd.sampler import sample
+
+    m = model(test_td, n_chains=2)
+    res = sample(m, tune=20, draws=8, chains=2, seed=1)
+    assert res["p"].shape == (2, 8) and res["i"].shape == (2, 8, 26, 10) and res["i_raw"].shape == (2, 8, 26, 10)
+    assert res["mean_ab_s_mu"].shape == (2, 26, 10)
+    np.testing.assert_allclose(res["mean_ab_n_mu"], res["ab_n_mu"].mean(1), rtol=1e-13)
+    np.testing.assert_allclose(res["mean_i"], res["i"].mean(1), atol=1e-15)
+    i_ref = O.constrain_infections(res["i_raw"][1, -1], np.asarray(test_td.pcrpos).T)
+    np.testing.assert_array_equal(res["i"][1, -1], i_ref)
+    lean = sample(m, tune=20, draws=8, chains=2, seed=1, record_deterministics=False, record_discrete=False)
+    assert "i" not in lean and "i_raw" not in lean
+    np.testing.assert_array_equal(lean["p"], res["p"])  # recording does not perturb the chain
+    np.testing.assert_array_equal(lean["mean_ab_n_mu"], res["mean_ab_n_mu"])
+    py = sample(m, tune=6, draws=3, chains=1, seed=1, native=False)
+    assert py["i"].shape == (1, 3, 26, 10)
+    m.close()

@@ -1,0 +1,76 @@
+"""The NUTS state machine of the native sampler (abd_nuts.hpp, HIP-free) on a closed-form target, CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    out = tmp_path_factory.mktemp("nuts") / "libnuts_harness.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "nuts_harness.cpp"), "-o", str(out)])
+    lib = C.CDLL(str(out))
+    dp = C.POINTER(C.c_double)
+    lib.nuts_harness_run.argtypes = [dp, dp, C.c_longlong, C.c_longlong, C.c_ulonglong, C.c_int, dp, dp]
+    lib.nuts_harness_run.restype = C.c_int
+
+    def run(mean, sd, tune, draws, seed, chains):
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        sd = np.ascontiguousarray(sd, dtype=np.float64)
+        q = np.empty((chains, draws, 17))
+        st = np.empty((chains, draws, 6))
+        rc = lib.nuts_harness_run(mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), tune, draws, seed, chains,
+                                  q.ctypes.data_as(dp), st.ctypes.data_as(dp))
+        assert rc == 0
+        return q, st
+
+    return run
+
+
+def _target():
+    rng = np.random.default_rng(5)
+    mean = rng.normal(size=17) * 3
+    sd = np.exp(rng.uniform(np.log(0.01), np.log(10.0), size=17))  # three decades of scales: needs the metric
+    return mean, sd
+
+
+def test_moments_of_a_badly_scaled_normal(harness):
+    mean, sd = _target()
+    q, st = harness(mean, sd, 1000, 2000, 11, 4)
+    assert not st[..., 5].any()  # no divergences on a normal
+    flat = q.reshape(-1, 17)
+    # effective sample size of NUTS on a normal is of the order of the draw count; allow 5 standard errors at ESS = n/4
+    se = sd / np.sqrt(flat.shape[0] / 4)
+    assert np.all(np.abs(flat.mean(0) - mean) < 5 * se), (flat.mean(0) - mean) / se
+    assert np.all(np.abs(flat.std(0) / sd - 1) < 0.12), flat.std(0) / sd
+    acc = st[..., 3].mean()
+    assert 0.7 < acc < 0.95, acc
+    # with an adapted metric the target is isotropic: trees stay short
+    assert st[..., 1].mean() < 4.5, st[..., 1].mean()
+    # logp stat is the target's logp at the draw
+    lp = -0.5 * (((q - mean) / sd) ** 2).sum(-1)
+    np.testing.assert_allclose(st[..., 0], lp, rtol=1e-10, atol=1e-10)
+
+
+def test_reproducible_and_streams_differ(harness):
+    mean, sd = _target()
+    q1, _ = harness(mean, sd, 200, 100, 3, 2)
+    q2, _ = harness(mean, sd, 200, 100, 3, 2)
+    q3, _ = harness(mean, sd, 200, 100, 4, 2)
+    np.testing.assert_array_equal(q1, q2)
+    assert not np.array_equal(q1, q3)
+    assert not np.array_equal(q1[0], q1[1])
+
+
+def test_step_size_settles_near_target(harness):
+    mean, sd = np.zeros(17), np.ones(17)
+    _, st = harness(mean, sd, 600, 600, 1, 4)
+    eps = st[..., 4]
+    assert np.all(eps == eps[:, :1])  # frozen after tuning
+    assert 0.3 < eps.mean() < 1.3  # 17-d unit normal: ~0.7 at 0.8 acceptance
+    assert abs(st[..., 3].mean() - 0.8) < 0.08

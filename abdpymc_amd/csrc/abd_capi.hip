@@ -53,6 +53,7 @@ struct AntigenDev {
   void* x = nullptr;       // sparse: R[K]
   uint8_t* g = nullptr;    // sparse: gap per obs
   int32_t* ptr = nullptr;  // sparse: (N+1)
+  int32_t* j = nullptr;    // sparse: individual per obs
   void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
 };
 
@@ -80,7 +81,9 @@ struct abd_ctx {
   int n_slots = 0;
   int n_cu = 256;
   int n_lg = 0;           // 64-individual lane groups
-  int blocks_x = 0;       // sparse kernel grid
+  int blocks_x = 0;       // sparse kernel grid (wave per individual)
+  int ob_n = 0, ob_s = 0, ob_c = 0;  // observation-lane kernel: workgroups per segment
+  bool obs_lanes = true;  // sparse lists: lane per observation (abd_obs.hpp) or wave per individual
   int blocks_max = 0;     // rows per chain in `partials`
   int cpw_forced = 0;
   int dense_blocks = 0;   // dense kernel grid.x
@@ -284,6 +287,13 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.g_s = c->s.g;
   a.ptr_n = c->n.ptr;
   a.ptr_s = c->s.ptr;
+  a.j_n = c->n.j;
+  a.j_s = c->s.j;
+  a.K_n = (int32_t)c->n.K;
+  a.K_s = (int32_t)c->s.K;
+  a.ob_n = c->ob_n;
+  a.ob_s = c->ob_s;
+  a.ob_c = c->ob_c;
   a.yx_n = c->n.yx;
   a.yx_s = c->s.yx;
   a.vw = c->vw;
@@ -336,6 +346,11 @@ hipError_t launch_sparse(int C, bool grad, dim3 grid, size_t lds, hipStream_t st
   }
 }
 
+template <typename R>
+hipError_t launch_obs(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+  return grad ? launch_k(abd_obs_kernel<R, true>, grid, lds, st, a) : launch_k(abd_obs_kernel<R, false>, grid, lds, st, a);
+}
+
 int pick_cpw(const abd_ctx* c, int n) {
   const int forced = c->cpw_forced;
   if (forced == 1 || forced == 2 || forced == 4) {
@@ -372,10 +387,14 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   base_args(c, a);
   a.n_chains = n;
   for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
-  const int cpw = pick_cpw(c, n);
+  const bool lanes = !c->dense && c->obs_lanes;
+  const int cpw = lanes ? 1 : pick_cpw(c, n);
   int blocks;
   size_t lds;
-  if (c->dense) {
+  if (lanes) {
+    blocks = c->ob_n + c->ob_s + c->ob_c;
+    lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
+  } else if (c->dense) {
     blocks = dense_blocks(c, cpw);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
   } else {
@@ -414,7 +433,10 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
   hipError_t le;
-  if (c->dense)
+  if (lanes)
+    le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, c->stream, a)
+                                     : launch_obs<double>(grad, grid, lds, c->stream, a);
+  else if (c->dense)
     le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, c->stream, a)
                                      : launch_dense<double>(cpw, grad, grid, lds, c->stream, a);
   else
@@ -572,12 +594,16 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
   }
   std::vector<R> y(std::max<size_t>(K, 1)), x(std::max<size_t>(K, 1));
   std::vector<uint8_t> g(std::max<size_t>(K, 1));
+  std::vector<int32_t> jj(std::max<size_t>(K, 1));
   for (size_t k = 0; k < K; ++k) {
     const int64_t src = so.order[k];
     y[k] = (R)o.od[src];
     x[k] = (R)o.log_dilution[src];
     g[k] = (uint8_t)o.idx_gap[src];
+    jj[k] = (int32_t)o.idx_ind[src];
   }
+  HIP_TRY(hipMalloc(&d.j, jj.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d.j, jj.data(), jj.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&d.y, y.size() * sizeof(R)));
   HIP_TRY(hipMalloc(&d.x, x.size() * sizeof(R)));
   HIP_TRY(hipMemcpy(d.y, y.data(), y.size() * sizeof(R), hipMemcpyHostToDevice));
@@ -608,6 +634,7 @@ void free_ctx(abd_ctx* c) {
     if (a->x) (void)hipFree(a->x);
     if (a->g) (void)hipFree(a->g);
     if (a->ptr) (void)hipFree(a->ptr);
+    if (a->j) (void)hipFree(a->j);
     if (a->yx) (void)hipFree(a->yx);
   }
   if (c->vw) (void)hipFree(c->vw);
@@ -717,7 +744,17 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   // dense kernel: 4 workgroups per CU = 4 waves per SIMD (<= 128 VGPRs, ~29 KB LDS each): one round, equal ranges
   int dbpc = 4;
   if (const char* e = std::getenv("ABD_DENSE_BLOCKS_PER_CU")) dbpc = std::max(1, std::atoi(e));
-  c->blocks_max = std::max(sparse_max, c->n_cu * 16);
+  {
+    const int cap = c->n_cu * 8;
+    c->ob_n = (int)std::min<int64_t>((d->n.n_obs + ABD_BLOCK - 1) / ABD_BLOCK, cap);
+    c->ob_s = (int)std::min<int64_t>((d->s.n_obs + ABD_BLOCK - 1) / ABD_BLOCK, cap);
+    c->ob_c = std::max(1, std::min((N + ABD_BLOCK - 1) / ABD_BLOCK, 64));
+    // lane per observation unless the lists are so full that a wave per individual keeps its 64 lanes busy
+    // for two rounds or more and amortises the constraint pass (measured crossover, tools/bench_sparse.py)
+    c->obs_lanes = d->s.n_obs + d->n.n_obs < (int64_t)256 * N;
+    if (const char* e = std::getenv("ABD_OBS_LANES")) c->obs_lanes = std::atoi(e) != 0;
+  }
+  c->blocks_max = std::max({sparse_max, c->n_cu * 16, c->ob_n + c->ob_s + c->ob_c});
   c->dense_blocks = std::min(c->n_cu * dbpc, c->blocks_max);
   if (const char* e = std::getenv("ABD_CPW")) c->cpw_forced = std::atoi(e);
   if (table_lds_bytes(G, 4, 16) > 160 * 1024) {

@@ -75,6 +75,11 @@ struct EvalArgs {
   const uint8_t* g_s;
   const int32_t* ptr_n;
   const int32_t* ptr_s;
+  const int32_t* j_n;  // individual of each observation (observation-lane kernel)
+  const int32_t* j_s;
+  int32_t K_n, K_s;          // list lengths
+  int32_t ob_n, ob_s, ob_c;  // observation-lane kernel: workgroups over the N list, the S list, the individuals
+  int32_t pad3_;
   // dense panels, gap-major [G][N] of {od, log_dilution}
   const void* yx_n;
   const void* yx_s;
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
   }
 }
 
+#include "abd_obs.hpp"
 #include "abd_gibbs.hpp"
 
 // ================================================================================================

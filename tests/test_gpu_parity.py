@@ -75,9 +75,13 @@ def test_dense_matches_literal_dense_oracle():
     assert abs(lp - ref) <= RTOL * abs(ref)
 
 
+# the two kernels for sparse observation lists: lane per observation (abd_obs.hpp, the default below 128
+# observations per individual and antigen) and wave per individual; ABD_OBS_LANES forces one (read at create)
+@pytest.mark.parametrize("lanes", ["1", "0"])
 @pytest.mark.parametrize("ignore", [False, True])
 @pytest.mark.parametrize("splits", [None, (10,), (0,), (26,), (8, 18)])
-def test_sparse_parity(ignore, splits):
+def test_sparse_parity(ignore, splits, lanes, monkeypatch):
+    monkeypatch.setenv("ABD_OBS_LANES", lanes)
     coh = random_sparse_cohort(37, 26, 900, 700, seed=9)
     ctx = _ctx(coh, splits, ignore)
     assert not ctx.is_dense
@@ -86,17 +90,42 @@ def test_sparse_parity(ignore, splits):
     lp, g = ctx.logp_dlogp(0, theta)
     lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh, splits, ignore)
     assert_close(lp, g, lp_ref, g_ref)
+    assert abs(ctx.logp(0, theta) - lp_ref) <= RTOL * abs(lp_ref)  # the logp-only instantiation
 
 
-def test_sparse_many_obs_per_individual():
-    """More than 64 observations per individual -> several lane chunks per wave."""
+@pytest.mark.parametrize("lanes", [None, "1", "0"])
+def test_sparse_many_obs_per_individual(lanes, monkeypatch):
+    """More than 64 observations per individual: several lane chunks per wave (wave per individual, which is
+    what the library picks by itself here) / individuals spanning several wavefronts (lane per observation)."""
+    if lanes is not None:
+        monkeypatch.setenv("ABD_OBS_LANES", lanes)
     coh = random_sparse_cohort(5, 40, 1500, 1100, seed=10)
-    ctx = _ctx(coh)
-    theta, i_raw, w = _state(coh, 13)
-    ctx.set_discrete(0, i_raw, w)
-    lp, g = ctx.logp_dlogp(0, theta)
-    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh)
-    assert_close(lp, g, lp_ref, g_ref)
+    ctx = _ctx(coh, (13, 30), n_chains=3)
+    thetas, refs = [], []
+    for c in range(3):
+        theta, i_raw, w = _state(coh, 13 + c)
+        ctx.set_discrete(c, i_raw, w)
+        thetas.append(theta)
+        refs.append(O.logp_dlogp(theta, i_raw, w, coh, (13, 30)))
+    lp, g = ctx.logp_dlogp_batch([0, 1, 2], np.array(thetas))
+    for c in range(3):
+        assert_close(lp[c], g[c], *refs[c])
+
+
+def test_sparse_lists_longer_than_the_grid(monkeypatch):
+    """The lane-per-observation grid is capped (8 workgroups per CU and list): lanes stride over longer lists."""
+    monkeypatch.setenv("ABD_OBS_LANES", "1")
+    coh = random_sparse_cohort(3000, 200, 700_000, 600_000, seed=11)
+    ctx = _ctx(coh, (70, 140), n_chains=2)
+    refs, thetas = [], []
+    for c in range(2):
+        theta, i_raw, w = _state(coh, 40 + c)
+        ctx.set_discrete(c, i_raw, w)
+        thetas.append(theta)
+        refs.append(O.logp_dlogp(theta, i_raw, w, coh, (70, 140)))
+    lp, g = ctx.logp_dlogp_batch([0, 1], np.array(thetas))
+    for c in range(2):
+        assert_close(lp[c], g[c], *refs[c])
 
 
 def test_empty_antigen_and_individuals_without_obs():

@@ -60,7 +60,7 @@ class _SamplerOpts(C.Structure):
         ("max_treedepth", C.c_int32),
         ("gibbs", C.c_int32),
         ("accumulate", C.c_int32),
-        ("reserved", C.c_int32),
+        ("chain_offset", C.c_int32),
     ]
 
 
@@ -367,9 +367,9 @@ class Context:
         return i, mun, mus
 
     def sampler(self, chains, theta0, tune: int, seed: int = 0, target_accept: float = 0.8, max_treedepth: int = 10,
-                gibbs: bool = True, accumulate: bool = False) -> "NativeSampler":
+                gibbs: bool = True, accumulate: bool = False, chain_offset: int = 0) -> "NativeSampler":
         """The compound step [NUTS; Gibbs sweep] for several chains in lock step, driven inside the library."""
-        return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate)
+        return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate, chain_offset)
 
     # -- measurement --------------------------------------------------------------------------
     def kernel_timing(self, enable: bool):
@@ -388,7 +388,8 @@ class Context:
 class NativeSampler:
     """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922), one launch per lock-step leapfrog."""
 
-    def __init__(self, ctx: Context, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate):
+    def __init__(self, ctx: Context, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate,
+                 chain_offset=0):
         self._ctx = ctx  # keeps the context alive
         self._lib = ctx._lib
         self._h = _P()
@@ -401,6 +402,7 @@ class NativeSampler:
         o.tune, o.seed = int(tune), int(seed) & (2**64 - 1)
         o.target_accept, o.max_treedepth = float(target_accept), int(max_treedepth)
         o.gibbs, o.accumulate = int(bool(gibbs)), int(bool(accumulate))
+        o.chain_offset = int(chain_offset)
         _check(self._lib, self._lib.abd_sampler_create(ctx._h, self.n, _ptr(ch, C.c_int32), _ptr(t0, C.c_double), C.byref(o),
                                                        C.byref(self._h)))
         ctx._samplers.add(self)

@@ -55,9 +55,13 @@ def write_posterior(res: dict, path: str, coords: dict) -> str:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
+    from . import distributed
     from .data import TiterData
     from .model import model
     from .sampler import sample
+
+    # one process per GPU under torch.distributed.run: chains are sharded, draws gathered at the end
+    dist, rank, world, local = distributed.init_from_env()
 
     data = TiterData.from_disk(args.ititers_data)  # abd.py:913
     splits = (
@@ -66,18 +70,37 @@ def main(argv=None) -> int:
         else data.calculate_splits(delta=args.split_delta, omicron=args.split_omicron)
     )  # abd.py:915-919
     chains = args.chains or args.cores or 1
-    m = model(data, splits=splits, ignore_pcrpos=args.ignore_pcrpos, n_chains=chains, device=args.device)  # abd.py:921
+    counts = distributed.split_counts(chains, world)
+    mine, first = counts[rank], sum(counts[:rank])
+    if mine == 0:
+        raise SystemExit(f"{chains} chains cannot be sharded over {world} processes: fewer chains than ranks")
+    device = args.device
+    if world > 1 and device < 0:
+        import torch
+
+        device = local % max(1, torch.cuda.device_count())
+    m = model(data, splits=splits, ignore_pcrpos=args.ignore_pcrpos, n_chains=mine, device=device)  # abd.py:921
     t0 = time.time()
 
     def progress(c, a, b):
         if a == b or a % max(1, b // 10) == 0:
-            print(f"chain {c}: {a}/{b} iterations, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+            print(f"chain {first + c}: {a}/{b} iterations, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
 
-    res = sample(m, tune=args.tune, draws=args.draws, chains=chains, seed=args.seed,
-                 record_deterministics=not args.no_deterministics, progress=progress)  # abd.py:922
-    out = write_posterior(res, args.netcdf, data.coords)
-    print(f"wrote {out}  ({chains} chains x {args.draws} draws on {m.ctx.device_name})", file=sys.stderr)
+    res = sample(m, tune=args.tune, draws=args.draws, chains=mine, seed=args.seed,
+                 record_deterministics=not args.no_deterministics, progress=progress, chain_offset=first)  # abd.py:922
+    name = m.ctx.device_name
     m.close()
+    if world > 1:
+        import torch
+
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else None
+        res = distributed.gather_results(res, counts, dist, dev)
+    if rank == 0:
+        out = write_posterior(res, args.netcdf, data.coords)
+        print(f"wrote {out}  ({chains} chains x {args.draws} draws on {world} x {name})", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

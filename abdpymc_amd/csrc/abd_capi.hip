@@ -955,8 +955,8 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   return ABD_OK;
 }
 
-int abd_gibbs_sweep(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
-                    int64_t* accepted, int64_t* proposed) {
+static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
+                            uint32_t stream_offset, int64_t* accepted, int64_t* proposed) {
   if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
@@ -980,6 +980,7 @@ int abd_gibbs_sweep(abd_ctx* c, int32_t n, const int32_t* chains, const double* 
       const double* t = theta + (size_t)(k0 + k) * ABD_N_THETA;
       ga.e.ch[k] = chain_par(c, chains[k0 + k], t);
       const Transformed tr = transform(t);
+      ga.stream[k] = (uint32_t)chains[k0 + k] + stream_offset;
       ga.theta0[k] = t[0];
       ga.theta7[k] = t[7];
       ga.is2_n[k] = 1.0 / (tr.sig_n * tr.sig_n);
@@ -1010,6 +1011,11 @@ int abd_gibbs_sweep(abd_ctx* c, int32_t n, const int32_t* chains, const double* 
     if (proposed) proposed[k] = (int64_t)counts[(size_t)k * 2 + 1];
   }
   return ABD_OK;
+}
+
+int abd_gibbs_sweep(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
+                    int64_t* accepted, int64_t* proposed) {
+  return gibbs_sweep_impl(c, n, chains, theta, seed, sweep, 0u, accepted, proposed);
 }
 
 int abd_get_discrete(abd_ctx* c, int32_t chain, int8_t* i_raw, int8_t* waner) {
@@ -1086,6 +1092,9 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
 // ---------------------------------------------------------------------------------------------------
 // Native compound sampler: lock-step NUTS over the chains + the device Gibbs sweep (abd_hip.h)
 // ---------------------------------------------------------------------------------------------------
+static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
+                            uint32_t stream_offset, int64_t* accepted, int64_t* proposed);
+
 struct abd_sampler {
   abd_ctx* c = nullptr;
   int n = 0;
@@ -1134,6 +1143,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     for (int b = a + 1; b < n; ++b)
       if (chains[a] == chains[b]) return fail(ABD_ERR_ARG, "chain %d listed twice", chains[a]);
   if (opts->tune < 0) return fail(ABD_ERR_ARG, "tune=%lld is negative", (long long)opts->tune);
+  if (opts->chain_offset < 0) return fail(ABD_ERR_ARG, "chain_offset=%d is negative", opts->chain_offset);
   if (opts->max_treedepth < 1 || opts->max_treedepth > abdnuts::MAX_DEPTH)
     return fail(ABD_ERR_ARG, "max_treedepth=%d outside [1, %d]", opts->max_treedepth, abdnuts::MAX_DEPTH);
   if (!(opts->target_accept > 0.0 && opts->target_accept < 1.0))
@@ -1161,7 +1171,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
       return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
     }
     s->ch[(size_t)k].init(theta0 + (size_t)k * ABD_N_THETA, s->lp[(size_t)k], s->gr.data() + (size_t)k * ABD_N_THETA,
-                          opts->seed, (uint64_t)chains[k], opts->tune, opts->max_treedepth, opts->target_accept);
+                          opts->seed, (uint64_t)((int64_t)chains[k] + opts->chain_offset), opts->tune, opts->max_treedepth, opts->target_accept);
   }
   if (opts->accumulate) {
     const size_t bytes = (size_t)n * 3 * c->G * c->N * sizeof(double);
@@ -1218,8 +1228,8 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
     if (s->o.gibbs) {
       for (int j = 0; j < n; ++j)
         std::memcpy(s->th.data() + (size_t)j * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
-      int rc = abd_gibbs_sweep(c, n, s->chains.data(), s->th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)s->it,
-                               acc.data(), prop.data());
+      int rc = gibbs_sweep_impl(c, n, s->chains.data(), s->th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)s->it,
+                                (uint32_t)s->o.chain_offset, acc.data(), prop.data());
       if (rc) return rc;
       rc = abd_logp_dlogp_batch(c, n, s->chains.data(), s->th.data(), s->lp.data(), s->gr.data());
       if (rc) return rc;

@@ -14,7 +14,7 @@
 // individual's G + 1 proposals in a uniformly random order IS the reference's sweep, at O(G) instead of
 // O(G N) work per proposal.
 //
-// Randomness: Philox4x32-10, counter (dim, individual, chain, 0), key (seed_lo ^ sweep * 0x9E3779B9, seed_hi):
+// Randomness: Philox4x32-10, counter (dim, individual, chain slot id + offset, 0), key (seed_lo ^ sweep * 0x9E3779B9, seed_hi):
 // word 0 orders the dims (low 9 bits replaced by the dim index, so keys are unique), word 1 is the transit
 // draw, word 2 the acceptance draw.  oracle/abd_oracle.c restates the same stream, so whole trajectories can
 // be compared bit for bit.
@@ -55,6 +55,7 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 struct GibbsArgs {
   EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)
   uint32_t seed_lo, seed_hi, sweep, pad_;
+  uint32_t stream[ABD_MAX_BATCH_K];  // third counter word of each chain: its slot id (+ the caller's offset)
   double theta0[ABD_MAX_BATCH_K];  // log p - log(1 - p)             = p_logodds__
   double theta7[ABD_MAX_BATCH_K];  // log p_waner - log(1 - p_waner) = ab_s_p_waner_logodds__
   double is2_n[ABD_MAX_BATCH_K];   // 1 / sigma_n^2
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   __syncthreads();
   const double theta0 = ga.theta0[c], theta7 = ga.theta7[c], is2_n = ga.is2_n[c], is2_s = ga.is2_s[c];
   const uint32_t k0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1 = ga.seed_hi;
+  const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(p.rw);
   int8_t* waner = const_cast<int8_t*>(p.waner);
   const int n_dims = G + 1;  // dims 0..G-1: i_raw[g, j]; dim G: ab_s_waner[j]
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
 
     // ---- random order and transit flags of this individual's dims ----
     for (int d = lane; d < n_dims; d += 64) {
-      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, (uint32_t)c, 0u, k0, k1);
+      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, cs, 0u, k0, k1);
       keyv[d] = (r.w[0] & ~0x1FFu) | (uint32_t)d;
       transit[d] = r.w[1] < ABD_TRANSIT_P_U32 ? 1 : 0;
     }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
         delta += ll_new - ll;
       }
       // metrop_select: keep the flip if delta > 0 or delta > log(u)
-      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, (uint32_t)c, 0u, k0, k1);
+      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, cs, 0u, k0, k1);
       const double u = ((double)r.w[2] + 0.5) * (1.0 / 4294967296.0);
       if (delta > 0.0 || delta > log(u)) {
 #pragma unroll

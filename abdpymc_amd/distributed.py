@@ -43,3 +43,54 @@ def gather_samples(block: np.ndarray, dist=None, device=None) -> np.ndarray:
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return np.stack([o.cpu().numpy() for o in out])
+
+
+def split_counts(n_chains: int, world: int) -> List[int]:
+    """Chains per rank for contiguous shards: the first ``n_chains % world`` ranks get one more."""
+    base, extra = divmod(n_chains, world)
+    return [base + (1 if r < extra else 0) for r in range(world)]
+
+
+def gather_results(res: dict, counts: List[int], dist=None, device=None) -> dict:
+    """
+    Concatenate per-rank result dicts (arrays with a leading local-chain axis) along the chain axis, in rank
+    order, on every rank.  Shards may differ in size by one chain: blocks are padded to the largest shard for
+    the all-gather and trimmed afterwards.  Integer arrays keep their dtype (they travel as float64, exact
+    for the 0/1 and count values recorded here).
+    """
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return res
+    cmax = max(counts)
+    out = {}
+    for key in sorted(res):
+        a = np.asarray(res[key])
+        if a.ndim == 0 or a.shape[0] != counts[dist.get_rank()]:
+            raise ValueError(f"{key}: leading axis {a.shape} is not this rank's chain count {counts[dist.get_rank()]}")
+        pad = np.zeros((cmax,) + a.shape[1:], dtype=np.float64)
+        pad[: a.shape[0]] = a
+        allb = gather_samples(pad, dist, device)
+        out[key] = np.concatenate([allb[r, : counts[r]] for r in range(len(counts))]).astype(a.dtype, copy=False)
+    return out
+
+
+def init_from_env():
+    """
+    One process per GPU under ``torch.distributed.run``: returns (dist, rank, world, local_rank), or
+    (None, 0, 1, 0) when not launched that way.  Backend "nccl" (RCCL over xGMI) when every rank has its own
+    GPU, "gloo" otherwise or when ABD_DIST_BACKEND says so.
+    """
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1, 0
+    import torch
+    import torch.distributed as dist
+
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("ABD_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, rank, world, local

@@ -279,11 +279,14 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
 
 def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
                   record_discrete: bool = True, progress: Optional[Callable[[int, int, int], None]] = None,
-                  target_accept: float = 0.8, max_treedepth: int = 10, chunk: int = 50) -> Dict[str, np.ndarray]:
+                  target_accept: float = 0.8, max_treedepth: int = 10, chunk: int = 50,
+                  chain_offset: int = 0) -> Dict[str, np.ndarray]:
     """
     All chains in lock step inside the library (``abd_sampler_*``): one launch per leapfrog for all chains, one
     launch per Gibbs sweep for all chains.  Posterior means of the three Deterministics are accumulated on the
     device and returned as ``mean_i``, ``mean_ab_n_mu``, ``mean_ab_s_mu``; per-draw copies only when asked for.
+    ``chain_offset`` is the global id of this process's first chain when chains are sharded over GPUs: local
+    chain c uses the random streams of global chain ``chain_offset + c``.
     """
     from .model import THETA_NAMES, constrain
 
@@ -292,11 +295,11 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
     pt = model.initial_point()
     q0 = np.empty((chains, len(THETA_NAMES)))
     for c in range(chains):
-        rng = np.random.default_rng([seed, c])
+        rng = np.random.default_rng([seed, chain_offset + c])
         ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
         q0[c] = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # jitter as pm.sample does
     smp = ctx.sampler(np.arange(chains), q0, tune=tune, seed=seed, target_accept=target_accept,
-                      max_treedepth=max_treedepth, gibbs=True, accumulate=True)
+                      max_treedepth=max_treedepth, gibbs=True, accumulate=True, chain_offset=chain_offset)
     n_grad = chains  # the evaluation at the starting points
     done = 0
 
@@ -357,12 +360,15 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
 
 def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
            progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True,
-           native: bool = True, record_discrete: bool = True) -> Dict[str, np.ndarray]:
+           native: bool = True, record_discrete: bool = True, chain_offset: int = 0) -> Dict[str, np.ndarray]:
     """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
     if chains > model.n_chains:
         raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
     if native and device_gibbs and hasattr(model.ctx, "sampler"):
-        return sample_native(model, tune, draws, chains, seed, record_deterministics, record_discrete, progress)
+        return sample_native(model, tune, draws, chains, seed, record_deterministics, record_discrete, progress,
+                             chain_offset=chain_offset)
+    if chain_offset:
+        raise ValueError("chain_offset needs the native sampler")
     per_chain = []
     for c in range(chains):
         cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None

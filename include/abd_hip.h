@@ -103,7 +103,8 @@ int abd_get_discrete(abd_ctx* ctx, int32_t chain, int8_t* i_raw, int8_t* waner);
  * (n x 17): what PyMC's BinaryGibbsMetropolis.astep does to these two variables inside pm.sample
  * (abd.py:922) -- every dim proposed with probability 0.8 in a uniformly random order, Metropolis
  * acceptance on the joint logp -- using the fact that a flip only changes its own individual's terms.
- * Randomness is Philox4x32-10 keyed by (seed, sweep).  accepted / proposed (n each) may be NULL. */
+ * Randomness is Philox4x32-10 keyed by (seed, sweep) with the chain's slot id in the counter: a chain's sweep
+ * does not depend on which other chains are listed.  accepted / proposed (n each) may be NULL. */
 int abd_gibbs_sweep(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta, uint64_t seed,
                     uint32_t sweep, int64_t* accepted, int64_t* proposed);
 
@@ -160,7 +161,8 @@ typedef struct abd_sampler_opts {
   int32_t max_treedepth;  /* 10 as pm.sample; at most 16 */
   int32_t gibbs;          /* 1: sweep [i_raw, ab_s_waner] after every NUTS transition; 0: continuous part only */
   int32_t accumulate;     /* 1: add i, ab_n_mu, ab_s_mu of every draw (iteration >= tune) into device sums */
-  int32_t reserved;
+  int32_t chain_offset;   /* chain slot k draws from random stream k + chain_offset: the global chain id when chains
+                             are sharded over processes (one per GPU), so draws do not depend on the world size */
 } abd_sampler_opts;
 
 #define ABD_N_STATS 10

@@ -5,7 +5,7 @@ import socket
 import numpy as np
 import pytest
 
-from abdpymc_amd.distributed import chain_ids_for_rank, gather_samples, shard_chains
+from abdpymc_amd.distributed import chain_ids_for_rank, gather_results, gather_samples, shard_chains, split_counts
 
 
 def _free_port():
@@ -23,6 +23,14 @@ def _worker(rank, world, port, q):
     # each rank "evaluates" its chains: block[c, k, :] = f(global chain id, draw)
     block = np.array([[[cid * 1000 + k + 0.5 * j for j in range(18)] for k in range(5)] for cid in chains])
     allb = gather_samples(block, dist)
+    # uneven shards (3 chains over 2 ranks) of a sampler result: padded for the all-gather, trimmed after
+    counts = split_counts(3, world)
+    first = sum(counts[:rank])
+    res = {"p": np.array([[10.0 * (first + c) + k for k in range(4)] for c in range(counts[rank])]),
+           "i_raw": np.array([np.full((4, 2, 3), first + c, dtype=np.int8) for c in range(counts[rank])])}
+    merged = gather_results(res, counts, dist)
+    assert merged["p"].shape == (3, 4) and merged["i_raw"].shape == (3, 4, 2, 3) and merged["i_raw"].dtype == np.int8
+    assert merged["p"][:, 1].tolist() == [1.0, 11.0, 21.0] and merged["i_raw"][:, 0, 0, 0].tolist() == [0, 1, 2]
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, chains, allb))
@@ -51,6 +59,9 @@ def test_two_rank_gather():
 
 def test_sharding_helpers():
     assert shard_chains(5, 2) == [[0, 2, 4], [1, 3]]
+    assert split_counts(32, 8) == [4] * 8 and split_counts(5, 3) == [2, 2, 1] and split_counts(2, 4) == [1, 1, 0, 0]
+    one = {"p": np.ones((2, 3))}
+    assert gather_results(one, [2]) is one  # single process: nothing to gather
     assert chain_ids_for_rank(3, 8, 4) == [12, 13, 14, 15]
     with pytest.raises(ValueError):
         chain_ids_for_rank(2, 2, 1)

@@ -199,3 +199,24 @@ def test_gpu_sweep_full_size_10000x200():
     assert (int(acc[2]), int(prop[2])) == (a_ref, p_ref)
     np.testing.assert_array_equal(i_gpu, i_ref)
     np.testing.assert_array_equal(w_gpu, w_ref)
+
+
+@gpu
+def test_gpu_sweep_streams_are_keyed_by_chain_slot():
+    """A chain's sweep depends on its slot id, not on its position in the call: sweeping slot 2 alone, listed
+    second, or in the second launch group of a 20-chain call gives the same bits; equal states in different
+    slots get different proposals."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(40, 30, seed=8))
+    co = c_oracle.COracle(coh, None)
+    theta, i_raw, w = _state(coh, 5)
+    ctx = _ctx(coh, n_chains=20)
+    refs = {c: co.gibbs_sweep(theta, i_raw, w, chain=c, seed=9, sweep=4) for c in (0, 2, 17)}
+    assert not np.array_equal(refs[0][0], refs[2][0]) and not np.array_equal(refs[0][0], refs[17][0])
+    for order in ([2], [5, 2], list(range(20))):
+        for c in range(20):
+            ctx.set_discrete(c, i_raw, w)
+        ctx.gibbs_sweep(order, np.tile(theta, (len(order), 1)), seed=9, sweep=4)
+        for c in (2, 17) if len(order) == 20 else (2,):
+            i_gpu, w_gpu = ctx.get_discrete(c)
+            np.testing.assert_array_equal(i_gpu, refs[c][0])
+            np.testing.assert_array_equal(w_gpu, refs[c][1])

@@ -50,7 +50,7 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 }
 
 #define ABD_TRANSIT_P_U32 3435973836u  // floor(0.8 * 2^32): propose iff word 1 < this   (transit_p = 0.8)
-#define ABD_GIBBS_WAVE_LDS 1856        // per wave: keys u32[260] + order u16[260] + transit u8[260], padded
+#define ABD_GIBBS_WAVE_LDS 3904        // per wave: keys u32[260] + order u16[260] + transit u8[260] (padded to 264) + log u f64[260]
 
 struct GibbsArgs {
   EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)
@@ -69,65 +69,118 @@ __device__ __forceinline__ double readfirstlane_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// -1/2 sum (q / sigma)^2 over this individual's observations for the given masks (terms that do not depend
-// on the discrete state are left out: they cancel in every difference)
-template <typename R, bool DENSE>
-__device__ __forceinline__ double individual_loglik(const EvalArgs& a, const ChainPar& p, int j, int lane,
-                                                    const uint64_t I[ABD_MAXT], const uint64_t V[ABD_MAXT], bool wj,
-                                                    const double2_t* tab_n, const double2_t* tab_sw,
-                                                    const double2_t* tab_ones, double is2_n, double is2_s,
-                                                    const YX<R> (&dn)[ABD_MAXT], const YX<R> (&ds)[ABD_MAXT]) {
-  const double2_t* tab_s = wj ? tab_sw : tab_ones;
-  double acc = 0.0;
+// ---- wave sum without LDS traffic: four DPP steps inside each row of 16 lanes, then the four row totals ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_uniform(double v) {  // the same value in every lane (wave-uniform)
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// This lane's share of -1/2 sum (q / sigma)^2 over the individual's observations for the given masks (terms
+// that do not depend on the discrete state are left out: they cancel in every difference).
+//
+// Dense panels: lane = gap 64 t + lane of round t; out[t] = both antigens' terms of that gap, for rounds
+// t >= r0 only -- the constraints and the responses are causal, so a flip whose first changed infection lies
+// in round r0 leaves earlier rounds as they were.  The response at a gap is the recurrence
+// T[g] = rho T[g-1] + e[g] unrolled per round: rho^(lane+1) x (T at the end of the previous round, a
+// wave-uniform carry) + the exposures of THIS round's word at or before the lane (power table).
+template <typename R>
+__device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& p, int lane, const uint64_t I[ABD_MAXT],
+                                             const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
+                                             double pwn, double pws, double is2_n, double is2_s,
+                                             const YX<R> (&dn)[ABD_MAXT], const YX<R> (&ds)[ABD_MAXT], int r0,
+                                             double& cvn, double& cvs, double (&out)[ABD_MAXT]) {
+  // cvn / cvs: lane t holds the response carried INTO round t (lane 0: 0).  Kept as one vector register each
+  // instead of 2 x 5 wave-uniform doubles: the masks already fill the scalar register file.
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;  // unused gradient outputs
-  if (DENSE) {
+  bool ci = false, civ = false;                   // any exposure in earlier rounds
+  const uint64_t le = (2ull << lane) - 1ull;      // bits at or before this lane (lane 63: all ones)
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
-      if (t < a.nt) {
-        const int g = t * 64 + lane;
-        // padding lanes (g >= G) must stay inside the power tables: their residual is multiplied by 0,
-        // but 0 * (garbage read past the table) could be NaN
-        const Resp rs = responses(g < a.G ? g : a.G - 1, t + 1, I, V, tab_n, tab_s);
-        const double guard = g < a.G ? 1.0 : 0.0;
-        const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-        const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    if (t < a.nt) {
+      if (t >= r0) {
+        double un = pwn * readlane_f64(cvn, t), us = pws * readlane_f64(cvs, t);
+        uint64_t m = I[t];
+        while (m) {  // wave-uniform loop over this word's infections
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const int idx = min(max(lane - b + 1, 0), a.G);  // 0 = "in the future"; padding lanes stay in the table
+          un += tab_n[idx].x;
+          us += tab_s[idx].x;
+        }
+        m = V[t];
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const int idx = min(max(lane - b + 1, 0), a.G);
+          us += tab_s[idx].x;
+        }
+        const bool cum_i = ci || (I[t] & le) != 0;
+        const bool cum_iv = civ || ((I[t] | V[t]) & le) != 0;
+        const double guard = t * 64 + lane < a.G ? 1.0 : 0.0;
+        const double an = p.init_n + (cum_i ? p.perm_n : 0.0) + p.temp_n * un;
+        const double as = p.init_s + (cum_iv ? p.perm_s : 0.0) + us;
         double q2n = 0.0, q2s = 0.0;
         obs_term<false>(an, (double)dn[t].x, (double)dn[t].y, p.b_n, p.d_n, guard, q2n, d0, d1, d2, d3);
         obs_term<false>(as, (double)ds[t].x, (double)ds[t].y, p.b_s, p.d_s, guard, q2s, d0, d1, d2, d3);
-        acc = fma(-0.5 * is2_n, q2n, acc);
-        acc = fma(-0.5 * is2_s, q2s, acc);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int ag = 0; ag < 2; ++ag) {
-      const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
-      const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
-      const void* yy = ag == 0 ? a.y_n : a.y_s;
-      const void* xx = ag == 0 ? a.x_n : a.x_s;
-      const int k0 = ptr[j], k1 = ptr[j + 1];
-      for (int kb = k0; kb < k1; kb += 64) {
-        const int k = kb + lane;
-        const bool in = k < k1;
-        const int kk = in ? k : k0;
-        const int g = gi[kk];
-        const double y = ld<R>(yy, kk), x = ld<R>(xx, kk);
-        const Resp rs = responses(g, a.nt, I, V, tab_n, tab_s);
-        const double guard = in ? 1.0 : 0.0;
-        double q2 = 0.0;
-        if (ag == 0) {
-          const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-          obs_term<false>(an, x, y, p.b_n, p.d_n, guard, q2, d0, d1, d2, d3);
-          acc = fma(-0.5 * is2_n, q2, acc);
-        } else {
-          const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
-          obs_term<false>(as, x, y, p.b_s, p.d_s, guard, q2, d0, d1, d2, d3);
-          acc = fma(-0.5 * is2_s, q2, acc);
+        out[t] = fma(-0.5 * is2_s, q2s, -0.5 * is2_n * q2n);
+        if (t + 1 < ABD_MAXT) {
+          cvn = lane == t + 1 ? readlane_f64(un, 63) : cvn;
+          cvs = lane == t + 1 ? readlane_f64(us, 63) : cvs;
         }
+      }
+      ci |= I[t] != 0;
+      civ |= (I[t] | V[t]) != 0;
+    }
+  }
+}
+
+// Sparse lists: lanes over the individual's observations; everything in one per-lane sum.
+template <typename R>
+__device__ __forceinline__ double sparse_terms(const EvalArgs& a, const ChainPar& p, int j, int lane, const uint64_t I[ABD_MAXT],
+                                               const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
+                                               double is2_n, double is2_s) {
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;  // unused gradient outputs
+  double acc = 0.0;
+#pragma unroll
+  for (int ag = 0; ag < 2; ++ag) {
+    const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
+    const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
+    const void* yy = ag == 0 ? a.y_n : a.y_s;
+    const void* xx = ag == 0 ? a.x_n : a.x_s;
+    const int k0 = ptr[j], k1 = ptr[j + 1];
+    for (int kb = k0; kb < k1; kb += 64) {
+      const int k = kb + lane;
+      const bool in = k < k1;
+      const int kk = in ? k : k0;
+      const int g = gi[kk];
+      const double y = ld<R>(yy, kk), x = ld<R>(xx, kk);
+      const Resp rs = responses(g, a.nt, I, V, tab_n, tab_s);
+      const double guard = in ? 1.0 : 0.0;
+      double q2 = 0.0;
+      if (ag == 0) {
+        const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
+        obs_term<false>(an, x, y, p.b_n, p.d_n, guard, q2, d0, d1, d2, d3);
+        acc = fma(-0.5 * is2_n, q2, acc);
+      } else {
+        const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
+        obs_term<false>(as, x, y, p.b_s, p.d_s, guard, q2, d0, d1, d2, d3);
+        acc = fma(-0.5 * is2_s, q2, acc);
       }
     }
   }
-  return readfirstlane_f64(wave_sum(acc));
+  return acc;
 }
 
 template <typename R, bool DENSE>
@@ -145,6 +198,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   uint32_t* keyv = reinterpret_cast<uint32_t*>(wbase);           // [260] sort key by dim
   uint16_t* order = reinterpret_cast<uint16_t*>(wbase + 1040);   // [260] dim by rank
   unsigned char* transit = wbase + 1040 + 520;                   // [260] 1 = propose, by dim
+  double* logu = reinterpret_cast<double*>(wbase + 1040 + 520 + 264);  // [260] log of the acceptance uniform, by dim
 
   const int c = blockIdx.y;  // one chain per block row
   const ChainPar& p = a.ch[c];
@@ -153,6 +207,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   fill_ones_table(tab_ones, tstride, tid, ABD_BLOCK);
   __syncthreads();
   const double theta0 = ga.theta0[c], theta7 = ga.theta7[c], is2_n = ga.is2_n[c], is2_s = ga.is2_s[c];
+  // rho^(lane + 1) = table entry lane + 2 (only used when a previous round exists, i.e. G > 64 >= lane + 1)
+  const double pwn = tabs[min(lane + 2, G)].x, pws = tabs[tstride + min(lane + 2, G)].x;
   const uint32_t k0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1 = ga.seed_hi;
   const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(p.rw);
@@ -188,6 +244,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, cs, 0u, k0, k1);
       keyv[d] = (r.w[0] & ~0x1FFu) | (uint32_t)d;
       transit[d] = r.w[1] < ABD_TRANSIT_P_U32 ? 1 : 0;
+      logu[d] = log(((double)r.w[2] + 0.5) * (1.0 / 4294967296.0));  // one log per lane and dim, not one per proposal
     }
     __builtin_amdgcn_wave_barrier();
     for (int d = lane; d < n_dims; d += 64) {  // rank = number of dims with a smaller key; order[rank] = dim
@@ -198,7 +255,16 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     }
     __builtin_amdgcn_wave_barrier();
 
-    double ll = individual_loglik<R, DENSE>(a, p, j, lane, I, V, wj, tabs, tabs + tstride, tab_ones, is2_n, is2_s, dn, ds);
+    // this lane's terms at the current state (dense: by round of 64 gaps, with the responses carried into
+    // each round; sparse: one sum in cur[0])
+    double cur[ABD_MAXT], cur_cn = 0.0, cur_cs = 0.0;
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) cur[t] = 0.0;
+    if (DENSE)
+      dense_rounds<R>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws : 1.0, is2_n, is2_s, dn, ds, 0,
+                      cur_cn, cur_cs, cur);
+    else
+      cur[0] = sparse_terms<R>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s);
 
     // ---- the sweep ----
     for (int k = 0; k < n_dims; ++k) {
@@ -206,10 +272,11 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       if (!__builtin_amdgcn_readfirstlane((int)transit[d])) continue;  // same value proposed: nothing to do
       ++n_prop;
       double delta;
-      uint64_t Rn[ABD_MAXT], In[ABD_MAXT];
+      uint64_t In[ABD_MAXT];
       bool wn = wj;
+      const uint64_t bit = d < G ? 1ull << (d & 63) : 0ull;  // the proposed flip of i_raw, in word d >> 6
       if (d < G) {
-        const uint64_t bit = 1ull << (d & 63);
+        uint64_t Rn[ABD_MAXT];
         bool was_one = false;
 #pragma unroll
         for (int t = 0; t < ABD_MAXT; ++t) {
@@ -225,30 +292,38 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
         wn = !wj;
         delta = wn ? theta7 : -theta7;  // Bernoulli(ab_s_waner | p_waner)   (abd.py:373)
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) {
-          Rn[t] = Rw[t];
-          In[t] = I[t];
-        }
+        for (int t = 0; t < ABD_MAXT; ++t) In[t] = I[t];
       }
-      bool same = wn == wj;
+      // first round of 64 gaps whose constrained infections differ (a waning flip touches every round)
+      int r0 = wn == wj ? ABD_MAXT : 0;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) same = same && In[t] == I[t];
-      double ll_new = ll;
-      if (!same) {  // the constrained infections (or the waning class) changed: re-evaluate this individual
-        ll_new = individual_loglik<R, DENSE>(a, p, j, lane, In, V, wn, tabs, tabs + tstride, tab_ones, is2_n, is2_s, dn, ds);
-        delta += ll_new - ll;
+      for (int t = ABD_MAXT - 1; t >= 0; --t)
+        if (In[t] != I[t]) r0 = min(r0, t);
+      double nxt[ABD_MAXT], nxt_cn = cur_cn, nxt_cs = cur_cs;
+#pragma unroll
+      for (int t = 0; t < ABD_MAXT; ++t) nxt[t] = cur[t];
+      if (r0 < ABD_MAXT) {  // something changed: re-evaluate this individual from there on
+        if (DENSE)
+          dense_rounds<R>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn, ds,
+                          r0, nxt_cn, nxt_cs, nxt);
+        else
+          nxt[0] = sparse_terms<R>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s);
+        double dl = 0.0;
+#pragma unroll
+        for (int t = 0; t < ABD_MAXT; ++t) dl += nxt[t] - cur[t];
+        delta += wave_sum_uniform(dl);
       }
       // metrop_select: keep the flip if delta > 0 or delta > log(u)
-      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, cs, 0u, k0, k1);
-      const double u = ((double)r.w[2] + 0.5) * (1.0 / 4294967296.0);
-      if (delta > 0.0 || delta > log(u)) {
+      if (delta > 0.0 || delta > readfirstlane_f64(logu[d])) {
 #pragma unroll
         for (int t = 0; t < ABD_MAXT; ++t) {
-          Rw[t] = Rn[t];
+          if (t == (d >> 6)) Rw[t] ^= bit;
           I[t] = In[t];
+          cur[t] = nxt[t];
         }
+        cur_cn = nxt_cn;
+        cur_cs = nxt_cs;
         wj = wn;
-        ll = ll_new;
         ++n_acc;
       }
     }

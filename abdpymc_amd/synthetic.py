@@ -29,6 +29,7 @@ class SyntheticCohort:
     y_s: np.ndarray  # od
     x_n: np.ndarray
     y_n: np.ndarray
+    i_true: np.ndarray = None  # (G, N) the infections the ODs were simulated from (parameter-recovery tests)
 
     @property
     def s_obs(self):
@@ -81,6 +82,11 @@ def theta_init(n_gaps: int) -> np.ndarray:
     )
 
 
+# what make_cohort simulates from (simulation.py:76-78, 104-108 defaults pushed through the model's equations)
+TRUTH = dict(ab_n_init=-2.0, ab_s_init=-2.0, ab_n_perm=2.0, ab_s_perm=2.0, ab_n_temp=1.5, ab_n_rho=0.95, ab_s_rho=0.95,
+             it_n_b=-2.2, it_s_b=-2.2, it_n_d=1.6, it_s_d=1.6, it_n_sigma=0.1, it_s_sigma=0.1)
+
+
 def make_cohort(n_inds: int, n_gaps: int, seed: int = SEED) -> SyntheticCohort:
     rng = np.random.default_rng(seed)
     G, N = n_gaps, n_inds
@@ -114,7 +120,7 @@ def make_cohort(n_inds: int, n_gaps: int, seed: int = SEED) -> SyntheticCohort:
 
     x_s, y_s = od(mu_s)
     x_n, y_n = od(mu_n)
-    return SyntheticCohort(G, N, vacs, pcrpos, idx_gap, idx_ind, x_s, y_s, x_n, y_n)
+    return SyntheticCohort(G, N, vacs, pcrpos, idx_gap, idx_ind, x_s, y_s, x_n, y_n, i_true.astype(np.int8))
 
 
 def make_chain_state(n_inds: int, n_gaps: int, chain: int, seed: int = SEED):

@@ -200,6 +200,22 @@ def main():
                    sample=f"{n_done} logp+grad evals of chain 0 at fresh thetas on the same cohort ({el:.1f} s), "
                           f"oracle/abd_oracle.c, OpenMP {cores} threads")
 
+    # ---- the whole compound step the path serves (informative; N=1 only): NUTS + Gibbs sweep, all chains in lock step
+    compound = None
+    if rank == 0 and world == 1:
+        iters = 12
+        smp = ctx.sampler(chains, thetas[W], tune=iters, seed=1)
+        t3 = time.perf_counter()
+        _, st = smp.run(iters)
+        dt3 = time.perf_counter() - t3
+        t4 = time.perf_counter()
+        ctx.gibbs_sweep(chains, thetas[W], seed=1, sweep=0)
+        sweep_ms = (time.perf_counter() - t4) * 1e3
+        smp.close()
+        compound = dict(chain_iterations_per_s=round(iters * C / dt3, 1), iterations=iters,
+                        leapfrogs_per_iteration=round(float(st["n_steps"].mean()), 1), gibbs_sweep_ms=round(sweep_ms, 3),
+                        note="abd_sampler_run from the bench's chain states, early tuning (step size still adapting)")
+
     if rank == 0:
         line = {
             "metric": "logp+grad evals/sec",
@@ -220,6 +236,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "sync_evals_per_s": round(sync_rate, 1),
+            "compound_step": compound,
             "device": ctx.device_name,
         }
         print(json.dumps(line), flush=True)

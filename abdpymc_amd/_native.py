@@ -61,6 +61,8 @@ class _SamplerOpts(C.Structure):
         ("gibbs", C.c_int32),
         ("accumulate", C.c_int32),
         ("chain_offset", C.c_int32),
+        ("dense_metric", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -99,7 +101,7 @@ SYMBOLS = {
     "abd_sampler_destroy": (None, [_P]),
     "abd_sampler_run": (C.c_int, [_P, C.c_int64, _D, _D]),
     "abd_sampler_means": (C.c_int, [_P, C.c_int32, _D, _D, _D, C.POINTER(C.c_int64)]),
-    "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D]),
+    "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
@@ -367,9 +369,11 @@ class Context:
         return i, mun, mus
 
     def sampler(self, chains, theta0, tune: int, seed: int = 0, target_accept: float = 0.8, max_treedepth: int = 10,
-                gibbs: bool = True, accumulate: bool = False, chain_offset: int = 0) -> "NativeSampler":
+                gibbs: bool = True, accumulate: bool = False, chain_offset: int = 0,
+                dense_metric: bool = False) -> "NativeSampler":
         """The compound step [NUTS; Gibbs sweep] for several chains in lock step, driven inside the library."""
-        return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate, chain_offset)
+        return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate, chain_offset,
+                             dense_metric)
 
     # -- measurement --------------------------------------------------------------------------
     def kernel_timing(self, enable: bool):
@@ -389,7 +393,7 @@ class NativeSampler:
     """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922), one launch per lock-step leapfrog."""
 
     def __init__(self, ctx: Context, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate,
-                 chain_offset=0):
+                 chain_offset=0, dense_metric=False):
         self._ctx = ctx  # keeps the context alive
         self._lib = ctx._lib
         self._h = _P()
@@ -403,6 +407,7 @@ class NativeSampler:
         o.target_accept, o.max_treedepth = float(target_accept), int(max_treedepth)
         o.gibbs, o.accumulate = int(bool(gibbs)), int(bool(accumulate))
         o.chain_offset = int(chain_offset)
+        o.dense_metric = int(bool(dense_metric))
         _check(self._lib, self._lib.abd_sampler_create(ctx._h, self.n, _ptr(ch, C.c_int32), _ptr(t0, C.c_double), C.byref(o),
                                                        C.byref(self._h)))
         ctx._samplers.add(self)
@@ -423,10 +428,17 @@ class NativeSampler:
         return out[0], out[1], out[2], n.value
 
     def adaptation(self, k: int):
+        """(diagonal of M^-1, step size) of the k-th chain."""
         inv_mass = np.empty(N_THETA)
         eps = C.c_double()
-        _check(self._lib, self._lib.abd_sampler_adaptation(self._h, int(k), _ptr(inv_mass, C.c_double), C.byref(eps)))
+        _check(self._lib, self._lib.abd_sampler_adaptation(self._h, int(k), _ptr(inv_mass, C.c_double), C.byref(eps), None))
         return inv_mass, eps.value
+
+    def metric(self, k: int) -> np.ndarray:
+        """Full M^-1 (17 x 17) of the k-th chain."""
+        m = np.empty((N_THETA, N_THETA))
+        _check(self._lib, self._lib.abd_sampler_adaptation(self._h, int(k), None, None, _ptr(m, C.c_double)))
+        return m
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -32,6 +32,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--seed", help="Random seed.", type=int, default=0)
     parser.add_argument("--device", help="HIP device ordinal.", type=int, default=-1)
     parser.add_argument("--no_deterministics", help="Do not record i / ab_n_mu / ab_s_mu per draw.", action="store_true")
+    parser.add_argument("--dense_metric", help="Adapt a full mass matrix (PyMC's init='adapt_full') instead of a diagonal one.",
+                        action="store_true")
     return parser
 
 
@@ -87,7 +89,8 @@ def main(argv=None) -> int:
             print(f"chain {first + c}: {a}/{b} iterations, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
 
     res = sample(m, tune=args.tune, draws=args.draws, chains=mine, seed=args.seed,
-                 record_deterministics=not args.no_deterministics, progress=progress, chain_offset=first)  # abd.py:922
+                 record_deterministics=not args.no_deterministics, progress=progress, chain_offset=first,
+                 dense_metric=args.dense_metric)  # abd.py:922
     name = m.ctx.device_name
     m.close()
     if world > 1:

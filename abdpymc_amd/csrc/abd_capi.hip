@@ -1171,7 +1171,8 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
       return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
     }
     s->ch[(size_t)k].init(theta0 + (size_t)k * ABD_N_THETA, s->lp[(size_t)k], s->gr.data() + (size_t)k * ABD_N_THETA,
-                          opts->seed, (uint64_t)((int64_t)chains[k] + opts->chain_offset), opts->tune, opts->max_treedepth, opts->target_accept);
+                          opts->seed, (uint64_t)((int64_t)chains[k] + opts->chain_offset), opts->tune, opts->max_treedepth, opts->target_accept,
+                          opts->dense_metric != 0);
   }
   if (opts->accumulate) {
     const size_t bytes = (size_t)n * 3 * c->G * c->N * sizeof(double);
@@ -1280,11 +1281,16 @@ int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* mu_n_me
   return ABD_OK;
 }
 
-int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size) {
+int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric) {
   if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
   if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
-  if (inv_mass) std::memcpy(inv_mass, s->ch[(size_t)k].nuts.inv_mass, sizeof(double) * ABD_N_THETA);
-  if (step_size) *step_size = s->ch[(size_t)k].nuts.eps;
+  const abdnuts::Nuts& nu = s->ch[(size_t)k].nuts;
+  if (inv_mass) std::memcpy(inv_mass, nu.inv_mass, sizeof(double) * ABD_N_THETA);
+  if (step_size) *step_size = nu.eps;
+  if (metric)
+    for (int r = 0; r < ABD_N_THETA; ++r)
+      for (int c = 0; c < ABD_N_THETA; ++c)
+        metric[r * ABD_N_THETA + c] = nu.dense ? nu.cov[r][c] : (r == c ? nu.inv_mass[r] : 0.0);
   return ABD_OK;
 }
 

@@ -21,6 +21,11 @@
 // variance 1 with weight 10).  PyMC itself is not importable offline: these constants are restated from its
 // documentation and the tests check the sampler on closed-form targets, not against PyMC draws.
 //
+// Optional dense metric (PyMC: init="adapt_full"): M^-1 = regularised covariance of the tuning draws, refreshed at
+// the end of windows that double in length; momenta p = L^-T z with M^-1 = L L^T.  This model's posterior is
+// strongly correlated (init and perm of an antigen trade off almost exactly), so the dense metric cuts the tree
+// depth from ~6 to ~3; the default stays diagonal, as pm.sample's is.
+//
 // No HIP in this file: tests/native compiles it with g++ against an analytic target.
 #pragma once
 #include <cmath>
@@ -160,6 +165,36 @@ struct MassAdapt {
   }
 };
 
+// running mean / scatter matrix for the dense metric
+struct Covariance {
+  double n = 0;
+  double mean[D];
+  double m2[D][D];
+  void reset() {
+    n = 0;
+    for (int r = 0; r < D; ++r) {
+      mean[r] = 0;
+      for (int c = 0; c < D; ++c) m2[r][c] = 0;
+    }
+  }
+  void add(const double* x) {
+    n += 1.0;
+    double d0[D];
+    for (int k = 0; k < D; ++k) {
+      d0[k] = x[k] - mean[k];
+      mean[k] += d0[k] / n;
+    }
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) m2[r][c] += d0[r] * (x[c] - mean[c]);
+  }
+  // Stan's shrinkage: (n / (n + 5)) cov + 1e-3 (5 / (n + 5)) I
+  void regularised(double out[D][D]) const {
+    const double w = n / (n + 5.0), e = 1e-3 * 5.0 / (n + 5.0);
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) out[r][c] = w * (n > 1 ? m2[r][c] / (n - 1.0) : 0.0) + (r == c ? e : 0.0);
+  }
+};
+
 struct Stats {
   double lp = 0, energy = 0, step_size = 0, mean_tree_accept = 0, max_energy_error = 0;
   int tree_depth = 0, n_steps = 0;
@@ -173,7 +208,10 @@ struct Phase {
 struct Nuts {
   // ---- persistent state of the chain ----
   double q[D], g[D], lp = 0;
-  double inv_mass[D];
+  double inv_mass[D];   // diagonal of M^-1
+  bool dense = false;   // use cov / chol instead of inv_mass
+  double cov[D][D];     // M^-1 (dense)
+  double chol[D][D];    // lower L with M^-1 = L L^T
   double eps = 0.1;
   int max_depth = 10;
   Rng rng;
@@ -198,8 +236,44 @@ struct Nuts {
     std::memcpy(g, g0, sizeof(g));
     lp = lp0;
     for (int k = 0; k < D; ++k) inv_mass[k] = 1.0;
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) cov[r][c] = chol[r][c] = r == c ? 1.0 : 0.0;
     rng.seed(seed, stream);
     active = false;
+  }
+  // install a dense M^-1; returns false (and keeps the old one) if it is not positive definite
+  bool set_dense_metric(const double m[D][D]) {
+    double l[D][D];
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double v = m[r][c];
+        for (int k = 0; k < c; ++k) v -= l[r][k] * l[c][k];
+        if (r == c) {
+          if (!(v > 0.0) || !std::isfinite(v)) return false;
+          l[r][c] = std::sqrt(v);
+        } else {
+          l[r][c] = v / l[c][c];
+        }
+      }
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) {
+        cov[r][c] = m[r][c];
+        chol[r][c] = c <= r ? l[r][c] : 0.0;
+      }
+    for (int k = 0; k < D; ++k) inv_mass[k] = m[k][k];
+    dense = true;
+    return true;
+  }
+  void velocity(const double* p, double* v) const {  // M^-1 p
+    if (!dense) {
+      for (int d = 0; d < D; ++d) v[d] = inv_mass[d] * p[d];
+      return;
+    }
+    for (int r = 0; r < D; ++r) {
+      double s = 0;
+      for (int c = 0; c < D; ++c) s += cov[r][c] * p[c];
+      v[r] = s;
+    }
   }
   void set_point(double lp0, const double* g0) {  // the discrete state changed under the chain
     lp = lp0;
@@ -207,20 +281,35 @@ struct Nuts {
   }
 
   double kinetic(const double* p) const {
-    double k = 0;
-    for (int d = 0; d < D; ++d) k += inv_mass[d] * p[d] * p[d];
+    double v[D], k = 0;
+    velocity(p, v);
+    for (int d = 0; d < D; ++d) k += v[d] * p[d];
     return 0.5 * k;
   }
   double dot_sharp(const double* r, const double* p) const {  // r . M^-1 p
-    double s = 0;
-    for (int d = 0; d < D; ++d) s += r[d] * inv_mass[d] * p[d];
+    double v[D], s = 0;
+    velocity(p, v);
+    for (int d = 0; d < D; ++d) s += r[d] * v[d];
     return s;
+  }
+  void draw_momentum(double* p) {  // p ~ N(0, M)
+    if (!dense) {
+      for (int d = 0; d < D; ++d) p[d] = rng.normal() / std::sqrt(inv_mass[d]);
+      return;
+    }
+    double z[D];
+    for (int d = 0; d < D; ++d) z[d] = rng.normal();
+    for (int r = D - 1; r >= 0; --r) {  // L^T p = z
+      double v = z[r];
+      for (int c = r + 1; c < D; ++c) v -= chol[c][r] * p[c];
+      p[r] = v / chol[r][r];
+    }
   }
 
   void begin() {
     if (max_depth > MAX_DEPTH) max_depth = MAX_DEPTH;
     double p0[D];
-    for (int d = 0; d < D; ++d) p0[d] = rng.normal() / std::sqrt(inv_mass[d]);
+    draw_momentum(p0);
     h0 = -lp + kinetic(p0);
     std::memcpy(left.q, q, sizeof(q));
     std::memcpy(left.p, p0, sizeof(p0));
@@ -327,10 +416,10 @@ struct Nuts {
   }
   void stage_leapfrog() {  // half kick + drift; the second half kick waits for the gradient
     const double ve = dir * eps;
-    for (int d = 0; d < D; ++d) {
-      p_half[d] = cur.p[d] + 0.5 * ve * cur.g[d];
-      req_q[d] = cur.q[d] + ve * inv_mass[d] * p_half[d];
-    }
+    double v[D];
+    for (int d = 0; d < D; ++d) p_half[d] = cur.p[d] + 0.5 * ve * cur.g[d];
+    velocity(p_half, v);
+    for (int d = 0; d < D; ++d) req_q[d] = cur.q[d] + ve * v[d];
   }
   void finish() {
     std::memcpy(q, prop_q, sizeof(q));
@@ -351,14 +440,29 @@ struct AdaptiveNuts {
   Nuts nuts;
   DualAveraging da;
   MassAdapt mass;
+  bool dense_metric = false;
+  Covariance cov_win;  // draws of the current slow window
+  int64_t slow_begin = 0, slow_end = 0, win_end = 0, win_len = 0;
+  double target = 0.8;
   int64_t tune = 0, it = 0;
   void init(const double* q0, double lp0, const double* g0, uint64_t seed, uint64_t stream, int64_t n_tune,
-            int max_depth, double target_accept) {
+            int max_depth, double target_accept, bool dense = false) {
     nuts.init(q0, lp0, g0, seed, stream);
     nuts.max_depth = max_depth;
     nuts.eps = 0.25 / std::pow((double)D, 0.25);
+    target = target_accept;
     da.init(nuts.eps, target_accept);
     mass.init(q0);
+    dense_metric = dense;
+    cov_win.reset();
+    // Stan's warm-up schedule: a fast interval (step size only, 7.5 %), slow windows that double (the first
+    // 2.5 %; each window's draws alone give the next metric: the early ones are still travelling to the
+    // typical set and must not linger in the estimate), a final fast interval (5 %)
+    slow_begin = n_tune * 75 / 1000;
+    slow_end = n_tune - n_tune * 50 / 1000;
+    win_len = n_tune * 25 / 1000 > 10 ? n_tune * 25 / 1000 : 10;
+    win_end = slow_begin + win_len;
+    if (win_end + 2 * win_len > slow_end) win_end = slow_end;  // no room for a second window: stretch this one
     tune = n_tune;
     it = 0;
   }
@@ -367,8 +471,24 @@ struct AdaptiveNuts {
   void end_transition() {
     if (it < tune) {
       nuts.eps = da.update(nuts.stats.mean_tree_accept);
-      // PyMC stops adapting the metric for the last stretch of tuning so the step size can settle
-      if (it < tune - tune / 10 - 1) mass.update(nuts.q, nuts.inv_mass);
+      if (!dense_metric) {
+        // PyMC stops adapting the metric for the last stretch of tuning so the step size can settle
+        if (it < tune - tune / 10 - 1) mass.update(nuts.q, nuts.inv_mass);
+      } else {
+        if (!nuts.dense && it < slow_end) mass.update(nuts.q, nuts.inv_mass);  // diagonal until the first window closes
+        if (it >= slow_begin && it < slow_end) {
+          cov_win.add(nuts.q);
+          if (it + 1 == win_end) {
+            double m[D][D];
+            cov_win.regularised(m);
+            if (cov_win.n > D && nuts.set_dense_metric(m)) da.init(nuts.eps, target);  // step size restarts
+            cov_win.reset();
+            win_len *= 2;
+            win_end += win_len;
+            if (win_end + 2 * win_len > slow_end) win_end = slow_end;
+          }
+        }
+      }
       if (it == tune - 1) nuts.eps = da.final_eps();
     }
     it += 1;

@@ -280,7 +280,7 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
 def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
                   record_discrete: bool = True, progress: Optional[Callable[[int, int, int], None]] = None,
                   target_accept: float = 0.8, max_treedepth: int = 10, chunk: int = 50,
-                  chain_offset: int = 0) -> Dict[str, np.ndarray]:
+                  chain_offset: int = 0, dense_metric: bool = False) -> Dict[str, np.ndarray]:
     """
     All chains in lock step inside the library (``abd_sampler_*``): one launch per leapfrog for all chains, one
     launch per Gibbs sweep for all chains.  Posterior means of the three Deterministics are accumulated on the
@@ -299,7 +299,8 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
         ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
         q0[c] = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # jitter as pm.sample does
     smp = ctx.sampler(np.arange(chains), q0, tune=tune, seed=seed, target_accept=target_accept,
-                      max_treedepth=max_treedepth, gibbs=True, accumulate=True, chain_offset=chain_offset)
+                      max_treedepth=max_treedepth, gibbs=True, accumulate=True, chain_offset=chain_offset,
+                      dense_metric=dense_metric)
     n_grad = chains  # the evaluation at the starting points
     done = 0
 
@@ -360,15 +361,16 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
 
 def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
            progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True,
-           native: bool = True, record_discrete: bool = True, chain_offset: int = 0) -> Dict[str, np.ndarray]:
+           native: bool = True, record_discrete: bool = True, chain_offset: int = 0,
+           dense_metric: bool = False) -> Dict[str, np.ndarray]:
     """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
     if chains > model.n_chains:
         raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
     if native and device_gibbs and hasattr(model.ctx, "sampler"):
         return sample_native(model, tune, draws, chains, seed, record_deterministics, record_discrete, progress,
-                             chain_offset=chain_offset)
-    if chain_offset:
-        raise ValueError("chain_offset needs the native sampler")
+                             chain_offset=chain_offset, dense_metric=dense_metric)
+    if chain_offset or dense_metric:
+        raise ValueError("chain_offset / dense_metric need the native sampler")
     per_chain = []
     for c in range(chains):
         cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None

@@ -163,6 +163,9 @@ typedef struct abd_sampler_opts {
   int32_t accumulate;     /* 1: add i, ab_n_mu, ab_s_mu of every draw (iteration >= tune) into device sums */
   int32_t chain_offset;   /* chain slot k draws from random stream k + chain_offset: the global chain id when chains
                              are sharded over processes (one per GPU), so draws do not depend on the world size */
+  int32_t dense_metric;   /* 0: diagonal M^-1, pm.sample's default; 1: full covariance of the tuning draws (PyMC:
+                             init="adapt_full") -- this posterior is strongly correlated and trees get ~8x shorter */
+  int32_t reserved;
 } abd_sampler_opts;
 
 #define ABD_N_STATS 10
@@ -189,8 +192,9 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
  * (G, N); any pointer may be NULL.  *n_draws receives the number of accumulated draws. */
 int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu_mean, double* ab_s_mu_mean,
                       int64_t* n_draws);
-/* Current diagonal of M^-1 (17) and step size of chain k. */
-int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size);
+/* Current diagonal of M^-1 (17) and step size of chain k; `metric` (17 x 17, may be NULL) receives the full
+ * M^-1 (the diagonal matrix when the metric is diagonal). */
+int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric);
 
 /* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
  * events on the context's stream; abd_kernel_time returns the accumulated kernel time and launch count

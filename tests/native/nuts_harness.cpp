@@ -2,11 +2,21 @@
 // independent-normal target whose moments are known in closed form.  Built by tests/test_nuts_native.py with g++.
 #include "abd_nuts.hpp"
 
-extern "C" int nuts_harness_run(const double* mean, const double* sd, long long tune, long long draws, unsigned long long seed,
-                                int n_chains, double* out_q, double* out_stats) {
+// target: independent normals (prec == NULL: mean, sd) or a correlated normal with precision matrix prec (17 x 17)
+extern "C" int nuts_harness_run(const double* mean, const double* sd, const double* prec, long long tune, long long draws,
+                                unsigned long long seed, int n_chains, int dense, double* out_q, double* out_stats) {
   using namespace abdnuts;
   auto eval = [&](const double* q, double* g) {
     double lp = 0;
+    if (prec) {
+      for (int r = 0; r < D; ++r) {
+        double s = 0;
+        for (int c = 0; c < D; ++c) s += prec[r * D + c] * (q[c] - mean[c]);
+        g[r] = -s;
+        lp -= 0.5 * s * (q[r] - mean[r]);
+      }
+      return lp;
+    }
     for (int d = 0; d < D; ++d) {
       const double z = (q[d] - mean[d]) / sd[d];
       lp -= 0.5 * z * z;
@@ -20,7 +30,7 @@ extern "C" int nuts_harness_run(const double* mean, const double* sd, long long 
     double q0[D], g0[D];
     for (int d = 0; d < D; ++d) q0[d] = mean[d] + sd[d] * (c % 2 ? 1.5 : -1.5);
     const double lp0 = eval(q0, g0);
-    ch[c].init(q0, lp0, g0, seed, (unsigned long long)c, tune, 10, 0.8);
+    ch[c].init(q0, lp0, g0, seed, (unsigned long long)c, tune, 10, 0.8, dense != 0);
   }
   for (long long it = 0; it < tune + draws; ++it) {
     for (int c = 0; c < n_chains; ++c) ch[c].nuts.begin();

@@ -16,15 +16,19 @@ def harness(tmp_path_factory):
                            os.path.join(ROOT, "tests", "native", "nuts_harness.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
     dp = C.POINTER(C.c_double)
-    lib.nuts_harness_run.argtypes = [dp, dp, C.c_longlong, C.c_longlong, C.c_ulonglong, C.c_int, dp, dp]
+    lib.nuts_harness_run.argtypes = [dp, dp, dp, C.c_longlong, C.c_longlong, C.c_ulonglong, C.c_int, C.c_int, dp, dp]
     lib.nuts_harness_run.restype = C.c_int
 
-    def run(mean, sd, tune, draws, seed, chains):
+    def run(mean, sd, tune, draws, seed, chains, prec=None, dense=False):
         mean = np.ascontiguousarray(mean, dtype=np.float64)
         sd = np.ascontiguousarray(sd, dtype=np.float64)
+        pp = None
+        if prec is not None:
+            prec = np.ascontiguousarray(prec, dtype=np.float64)
+            pp = prec.ctypes.data_as(dp)
         q = np.empty((chains, draws, 17))
         st = np.empty((chains, draws, 6))
-        rc = lib.nuts_harness_run(mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), tune, draws, seed, chains,
+        rc = lib.nuts_harness_run(mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), pp, tune, draws, seed, chains, int(dense),
                                   q.ctypes.data_as(dp), st.ctypes.data_as(dp))
         assert rc == 0
         return q, st
@@ -74,3 +78,31 @@ def test_step_size_settles_near_target(harness):
     assert np.all(eps == eps[:, :1])  # frozen after tuning
     assert 0.3 < eps.mean() < 1.3  # 17-d unit normal: ~0.7 at 0.8 acceptance
     assert abs(st[..., 3].mean() - 0.8) < 0.08
+
+
+def _correlated_target():
+    """Pairs of variables that trade off almost exactly (like init / perm of an antigen in the abd posterior)."""
+    rng = np.random.default_rng(9)
+    cov = np.diag(np.exp(rng.uniform(np.log(0.05), np.log(2.0), size=17)) ** 2)
+    for a, b in ((0, 1), (4, 5), (10, 12)):
+        cov[a, b] = cov[b, a] = -0.995 * np.sqrt(cov[a, a] * cov[b, b])
+    return rng.normal(size=17), cov
+
+
+def test_dense_metric_shortens_trees_on_a_correlated_normal(harness):
+    mean, cov = _correlated_target()
+    prec = np.linalg.inv(cov)
+    sd = np.sqrt(np.diag(cov))
+    qd, sd_stats = harness(mean, sd, 1000, 1500, 21, 4, prec=prec, dense=True)
+    q1, s1_stats = harness(mean, sd, 1000, 1500, 21, 4, prec=prec, dense=False)
+    for q, st in ((qd, sd_stats), (q1, s1_stats)):
+        flat = q.reshape(-1, 17)
+        assert not st[..., 5].any()
+        se = sd / np.sqrt(flat.shape[0] / 8)
+        assert np.all(np.abs(flat.mean(0) - mean) < 5 * se), (flat.mean(0) - mean) / se
+        emp = np.cov(flat.T)
+        assert np.all(np.abs(np.sqrt(np.diag(emp)) / sd - 1) < 0.15)
+        assert emp[0, 1] / np.sqrt(emp[0, 0] * emp[1, 1]) < -0.98  # the trade-off is there
+    depth_dense, depth_diag = sd_stats[..., 1].mean(), s1_stats[..., 1].mean()
+    assert depth_dense < 3.6 and depth_diag > depth_dense + 1.5, (depth_dense, depth_diag)
+    assert 0.7 < sd_stats[..., 3].mean() < 0.95

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--draws", type=int, default=100)
     ap.add_argument("--no-record", action="store_true")
     ap.add_argument("--python", action="store_true", help="the Python driver instead of the native one")
+    ap.add_argument("--dense", action="store_true", help="dense metric")
     a = ap.parse_args()
     if a.cohort == "default":
         from tests.test_data_loader import default_cohort
@@ -38,7 +39,10 @@ def main():
         m = model(td, n_chains=a.chains)
     t0 = time.perf_counter()
     kw = dict(native=not a.python) if "native" in sampler.sample.__code__.co_varnames else {}
-    res = sampler.sample(m, a.tune, a.draws, chains=a.chains, seed=1, record_deterministics=not a.no_record, **kw)
+    if a.dense:
+        kw["dense_metric"] = True
+    res = sampler.sample(m, a.tune, a.draws, chains=a.chains, seed=1, record_deterministics=not a.no_record,
+                         record_discrete=not a.no_record, **kw)
     dt = time.perf_counter() - t0
     iters = a.tune + a.draws
     print(f"{a.cohort}: {a.chains} chains x {iters} iterations in {dt:.2f} s = {a.chains * iters / dt:.1f} chain-iterations/s; "

@@ -11,11 +11,13 @@ from abdpymc_amd.sampler import sample
 
 N, G = int(sys.argv[1]), int(sys.argv[2])
 tune, draws, chains = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+dense = len(sys.argv) > 6 and sys.argv[6] == "dense"
 sc = synthetic.make_cohort(N, G, seed=77)
 td = TiterData.from_arrays(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos)
 m = model(td, n_chains=chains)
 t0 = time.perf_counter()
-res = sample(m, tune, draws, chains=chains, seed=3, record_deterministics=False, record_discrete=False)
+res = sample(m, tune, draws, chains=chains, seed=3, record_deterministics=False, record_discrete=False, dense_metric=dense)
+print(f"dense={dense} n_steps {res['stat_n_steps'].mean():.1f}", end=" ")
 print(f"{time.perf_counter() - t0:.2f} s; depth {res['stat_tree_depth'].mean():.2f}; div {int(res['stat_diverging'].sum())}; gibbs acc {res['stat_gibbs_accept'].mean():.4f}")
 for k, v in synthetic.TRUTH.items():
     d = res[k]

@@ -108,6 +108,7 @@ struct abd_ctx {
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots + 1][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
+  double* d_det = nullptr;                 // staging of abd_deterministics: mu_n, mu_s (G*N doubles each), i (G*N bytes)
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
   int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
   std::vector<ResultSlot> results;
@@ -649,6 +650,7 @@ void free_ctx(abd_ctx* c) {
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->d_det) (void)hipFree(c->d_det);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -927,31 +929,23 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
   const size_t cells = (size_t)c->G * c->N;
-  int8_t* d_i = nullptr;
-  double *d_n = nullptr, *d_s = nullptr;
-  hipError_t e = hipSuccess;
-  if (i) e = hipMalloc(&d_i, cells);
-  if (e == hipSuccess && mu_n) e = hipMalloc(&d_n, cells * sizeof(double));
-  if (e == hipSuccess && mu_s) e = hipMalloc(&d_s, cells * sizeof(double));
-  if (e == hipSuccess) {
-    EvalArgs a;
-    base_args(c, a);
-    a.n_chains = 1;
-    a.ch[0] = chain_par(c, chain, theta);
-    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
-    const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, d_i, d_n, d_s,
-                       (double*)nullptr);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess && i) e = hipMemcpy(i, d_i, cells, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && mu_n) e = hipMemcpy(mu_n, d_n, cells * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && mu_s) e = hipMemcpy(mu_s, d_s, cells * sizeof(double), hipMemcpyDeviceToHost);
-  if (d_i) (void)hipFree(d_i);
-  if (d_n) (void)hipFree(d_n);
-  if (d_s) (void)hipFree(d_s);
-  if (e != hipSuccess) return fail(ABD_ERR_HIP, "deterministics: %s", hipGetErrorString(e));
+  if (!c->d_det) HIP_TRY(hipMalloc(&c->d_det, cells * (2 * sizeof(double) + 1)));  // staging, kept for the next draw
+  double* d_n = c->d_det;
+  double* d_s = c->d_det + cells;
+  int8_t* d_i = reinterpret_cast<int8_t*>(c->d_det + 2 * cells);
+  EvalArgs a;
+  base_args(c, a);
+  a.n_chains = 1;
+  a.ch[0] = chain_par(c, chain, theta);
+  const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
+  const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+  hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, i ? d_i : (int8_t*)nullptr,
+                     mu_n ? d_n : (double*)nullptr, mu_s ? d_s : (double*)nullptr, (double*)nullptr);
+  HIP_TRY(hipGetLastError());
+  if (mu_n) HIP_TRY(hipMemcpyAsync(mu_n, d_n, cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (mu_s) HIP_TRY(hipMemcpyAsync(mu_s, d_s, cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (i) HIP_TRY(hipMemcpyAsync(i, d_i, cells, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
 }
 

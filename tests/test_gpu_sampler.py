@@ -295,3 +295,20 @@ def test_dense_metric_on_the_model_posterior():
     s = dense["ab_n_init"] + dense["ab_n_perm"]
     assert s.std() < 0.3 * dense["ab_n_init"].std()
     m.close()
+
+
+def test_more_chains_than_one_launch_holds(test_td):
+    """20 chains: every lock-step leapfrog and every sweep is split into launches of <= 16 chains."""
+    from abdpymc_amd.model import model
+
+    m = model(test_td, n_chains=20)
+    q0 = _start(m, 20)
+    smp = m.ctx.sampler(np.arange(20), q0, tune=30, seed=2)
+    th, st = smp.run(40)
+    assert np.all(np.isfinite(st["lp"])) and th.shape == (20, 40, 17)
+    for c in (0, 15, 16, 19):
+        lp, _ = m.ctx.logp_dlogp(c, th[c, -1])
+        assert abs(lp - st["lp"][c, -1]) <= 1e-11 * abs(lp)
+    # all chains differ (own random streams, also across the two launch groups)
+    assert len({tuple(np.round(th[c, -1], 12)) for c in range(20)}) == 20
+    m.close()

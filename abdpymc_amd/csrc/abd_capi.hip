@@ -103,6 +103,7 @@ struct abd_ctx {
   } pending;
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
+  bool xcd_remap = true;
   int fin_rows = 2;
   double prior_const = 0.0;
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots + 1][n_slots][ABD_NOUT]
@@ -408,6 +409,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   c->pbuf ^= 1;
   a.partials = c->partials[buf];
   a.fin_rows = c->fin_rows;
+  a.xcd_remap = c->xcd_remap ? 1 : 0;
   if (c->dense && c->fuse_finalize && c->pending.on && c->pending.n <= blocks) {
     // this launch's first workgroups sum the previous launch's partials
     a.prev_partials = c->partials[c->pending.buf];
@@ -793,6 +795,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   }
   for (int b = 0; b < 2; ++b) CREATE_TRY(hipMalloc(&c->partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
   if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ABD_XCD_REMAP")) c->xcd_remap = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
   const size_t out_bytes = (size_t)(kResultSlots + 1) * c->n_slots * ABD_NOUT * sizeof(double);
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));

@@ -44,11 +44,19 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const int cbase = blockIdx.y * CB;
   const ChainPar& p = a.ch[cbase + c];
 
-  // the first workgroups of grid row 0 first sum the previous launch's partials (see EvalArgs::prev_*)
+  // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2: give every XCD one contiguous
+  // eighth of the plane, so that the ~G/rows-per-range neighbouring ranges that re-read one lane group's packed
+  // words (and the rows shared at range borders) find them in their own L2 instead of fetching them again.
+  // blk = this workgroup's position in range order (a bijection of blockIdx.x for any grid size).
+  const int nblk = (int)gridDim.x;
+  const int xcd = (int)blockIdx.x % 8, q8 = nblk / 8, rem8 = nblk % 8;
+  const int blk = a.xcd_remap ? xcd * q8 + min(xcd, rem8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+
+  // the workgroups that own the first ranges of grid row 0 first sum the previous launch's partials (EvalArgs::prev_*)
   const int n_fin = blockIdx.y == 0 ? a.prev_n_chains : 0;
-  if ((int)blockIdx.x < n_fin) {
-    finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blockIdx.x * a.prev_blocks * ABD_NOUT, a.prev_blocks,
-                   a.prev_out + (int64_t)blockIdx.x * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.prev_tag);
+  if (blk < n_fin) {
+    finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blk * a.prev_blocks * ABD_NOUT, a.prev_blocks,
+                   a.prev_out + (int64_t)blk * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.prev_tag);
     __syncthreads();  // the scratch becomes the power tables
   }
 
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   // actually carried, so results are bit-identical either way.
   const int64_t rows_total = (int64_t)a.n_lg * G;
   const int64_t n_ranges = (int64_t)gridDim.x * NSUB;
-  const int64_t r = (int64_t)blockIdx.x * NSUB + sub;
+  const int64_t r = (int64_t)blk * NSUB + sub;
   const int64_t n_short = blockIdx.y == 0 ? min((int64_t)a.n_chains, n_ranges) : 0;
   const int64_t e_fin = (NSUB == 1 && (rows_total + n_short * a.fin_rows) / n_ranges >= 2 * a.fin_rows) ? a.fin_rows : 0;
   const int64_t virt = rows_total + n_short * e_fin;
@@ -226,6 +234,6 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
-    a.partials[((int64_t)(cbase + cc) * gridDim.x + blockIdx.x) * ABD_NOUT + k] = v;
+    a.partials[((int64_t)(cbase + cc) * gridDim.x + blk) * ABD_NOUT + k] = v;  // rows in range order
   }
 }

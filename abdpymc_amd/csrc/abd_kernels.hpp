@@ -93,7 +93,8 @@ struct EvalArgs {
   const double* prev_partials;
   double* prev_out;
   int32_t prev_n_chains, prev_blocks;
-  int32_t fin_rows, pad2_;  // gap rows the finalizing workgroups are excused from
+  int32_t fin_rows;    // gap rows the finalizing workgroups are excused from
+  int32_t xcd_remap;   // dense kernel: workgroup -> range mapping that keeps neighbouring ranges on one XCD
   double prev_tag;          // completion tag of the previous launch (see finalize_chain)
   int32_t G, N, nt, n_chunks;
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)

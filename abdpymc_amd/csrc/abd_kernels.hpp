@@ -330,10 +330,11 @@ __device__ __forceinline__ void obs_term(double a, double x, double y, double b,
   if (GUARD) q *= guard;  // guard = 0 on padding lanes, else 1
   q2 = fma(q, q, q2);
   if (GRAD) {
-    const double h = q * (s * (e * s));    // 1 - s = e s
+    const double u = q * s;
+    sqs += u;
+    const double h = fma(-u, s, u);  // q s (1 - s)
     sh += h;
     shx = fma(h, amx, shx);
-    sqs = fma(q, s, sqs);
     h_out = h;
   }
 }

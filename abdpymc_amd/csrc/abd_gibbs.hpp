@@ -95,12 +95,20 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {  // the same valu
 // in round r0 leaves earlier rounds as they were.  The response at a gap is the recurrence
 // T[g] = rho T[g-1] + e[g] unrolled per round: rho^(lane+1) x (T at the end of the previous round, a
 // wave-uniform carry) + the exposures of THIS round's word at or before the lane (power table).
-template <typename R>
+//
+// PROPOSAL: the rounds of a proposed state are evaluated one at a time and the walk stops as soon as the
+// proposal cannot be accepted any more.  Every term is <= 0, so the rounds not yet evaluated can raise the
+// log-ratio by at most minus their CURRENT sums (suf: lane t = that bound for rounds >= t); once
+// delta + bound < log u the outcome is settled.  A new infection moves the titers of its own round by a
+// whole boost and is usually rejected there: ~1 round per proposal instead of ~3 at G = 200.  The test is
+// exact (it never changes a decision), with a relative margin of 1e-9 against rounding in the bound.
+template <typename R, bool PROPOSAL>
 __device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& p, int lane, const uint64_t I[ABD_MAXT],
                                              const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
                                              double pwn, double pws, double is2_n, double is2_s,
                                              const YX<R> (&dn)[ABD_MAXT], const YX<R> (&ds)[ABD_MAXT], int r0,
-                                             double& cvn, double& cvs, double (&out)[ABD_MAXT]) {
+                                             double& cvn, double& cvs, double (&out)[ABD_MAXT],
+                                             const double (&cur)[ABD_MAXT], double suf, double logu, double& delta, bool& dead) {
   // cvn / cvs: lane t holds the response carried INTO round t (lane 0: 0).  Kept as one vector register each
   // instead of 2 x 5 wave-uniform doubles: the masks already fill the scalar register file.
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;  // unused gradient outputs
@@ -109,7 +117,7 @@ __device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& 
 #pragma unroll
   for (int t = 0; t < ABD_MAXT; ++t) {
     if (t < a.nt) {
-      if (t >= r0) {
+      if (t >= r0 && !dead) {
         double un = pwn * readlane_f64(cvn, t), us = pws * readlane_f64(cvs, t);
         uint64_t m = I[t];
         while (m) {  // wave-uniform loop over this word's infections
@@ -138,6 +146,11 @@ __device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& 
         if (t + 1 < ABD_MAXT) {
           cvn = lane == t + 1 ? readlane_f64(un, 63) : cvn;
           cvs = lane == t + 1 ? readlane_f64(us, 63) : cvs;
+        }
+        if (PROPOSAL) {
+          delta += wave_sum_uniform(out[t] - cur[t]);
+          const double rest = t + 1 < ABD_MAXT ? readlane_f64(suf, t + 1) : 0.0;
+          if (delta + rest < logu - 1e-9 * (fabs(delta) + rest + 1.0)) dead = true;
         }
       }
       ci |= I[t] != 0;
@@ -260,11 +273,25 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     double cur[ABD_MAXT], cur_cn = 0.0, cur_cs = 0.0;
 #pragma unroll
     for (int t = 0; t < ABD_MAXT; ++t) cur[t] = 0.0;
-    if (DENSE)
-      dense_rounds<R>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws : 1.0, is2_n, is2_s, dn, ds, 0,
-                      cur_cn, cur_cs, cur);
-    else
+    double suf = 0.0;  // lane t: -(sum of the current terms of rounds >= t) >= 0, the most those rounds can give back
+    auto refresh_bounds = [&]() {
+      double accb = 0.0;
+      suf = 0.0;
+#pragma unroll
+      for (int t = ABD_MAXT - 1; t >= 0; --t) {
+        if (t < nt) accb -= wave_sum_uniform(cur[t]);
+        suf = lane == t ? accb : suf;
+      }
+    };
+    if (DENSE) {
+      double unused_delta = 0.0;
+      bool unused_dead = false;
+      dense_rounds<R, false>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws : 1.0, is2_n, is2_s, dn, ds,
+                             0, cur_cn, cur_cs, cur, cur, 0.0, 0.0, unused_delta, unused_dead);
+      refresh_bounds();
+    } else {
       cur[0] = sparse_terms<R>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s);
+    }
 
     // ---- the sweep ----
     for (int k = 0; k < n_dims; ++k) {
@@ -302,19 +329,19 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       double nxt[ABD_MAXT], nxt_cn = cur_cn, nxt_cs = cur_cs;
 #pragma unroll
       for (int t = 0; t < ABD_MAXT; ++t) nxt[t] = cur[t];
+      const double log_u = readfirstlane_f64(logu[d]);
+      bool dead = false;  // dense: settled as a rejection before all rounds were evaluated
       if (r0 < ABD_MAXT) {  // something changed: re-evaluate this individual from there on
-        if (DENSE)
-          dense_rounds<R>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn, ds,
-                          r0, nxt_cn, nxt_cs, nxt);
-        else
+        if (DENSE) {
+          dense_rounds<R, true>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn,
+                                ds, r0, nxt_cn, nxt_cs, nxt, cur, suf, log_u, delta, dead);
+        } else {
           nxt[0] = sparse_terms<R>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s);
-        double dl = 0.0;
-#pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) dl += nxt[t] - cur[t];
-        delta += wave_sum_uniform(dl);
+          delta += wave_sum_uniform(nxt[0] - cur[0]);
+        }
       }
       // metrop_select: keep the flip if delta > 0 or delta > log(u)
-      if (delta > 0.0 || delta > readfirstlane_f64(logu[d])) {
+      if (!dead && (delta > 0.0 || delta > log_u)) {
 #pragma unroll
         for (int t = 0; t < ABD_MAXT; ++t) {
           if (t == (d >> 6)) Rw[t] ^= bit;
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
         }
         cur_cn = nxt_cn;
         cur_cs = nxt_cs;
+        if (DENSE) refresh_bounds();
         wj = wn;
         ++n_acc;
       }

@@ -798,7 +798,10 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_XCD_REMAP")) c->xcd_remap = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
   const size_t out_bytes = (size_t)(kResultSlots + 1) * c->n_slots * ABD_NOUT * sizeof(double);
-  CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped));
+  // COHERENT (fine-grained) on purpose: synchronous calls poll a completion tag in this memory while the stream
+  // is still running.  With hipHostMallocMapped alone the allocation is non-coherent: the GPU caches it and the
+  // two 64-byte halves of a result row could reach the host in either order (tag visible, data stale).
+  CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));

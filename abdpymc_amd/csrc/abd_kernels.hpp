@@ -383,7 +383,7 @@ __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int
 #pragma unroll
     for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];
     __threadfence_system();
-    out[ABD_NOUT - 1] = tag;
+    __hip_atomic_store(out + (ABD_NOUT - 1), tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

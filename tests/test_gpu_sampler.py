@@ -312,3 +312,28 @@ def test_more_chains_than_one_launch_holds(test_td):
     # all chains differ (own random streams, also across the two launch groups)
     assert len({tuple(np.round(th[c, -1], 12)) for c in range(20)}) == 20
     m.close()
+
+
+def test_back_to_back_synchronous_calls_are_deterministic(test_td):
+    """Regression: the NUTS driver issues synchronous evaluations ~17 us apart and polls their completion tag in
+    mapped host memory.  That memory has to be COHERENT (fine-grained): with a plain mapped allocation the two
+    64-byte halves of a result row could reach the host out of order -- tag visible, first half stale -- and about
+    one run in fifty took a different trajectory.  Same seed, many runs: identical bits every time."""
+    from abdpymc_amd.model import model
+
+    m = model(test_td, n_chains=2)
+    pt = m.initial_point()
+    ref = None
+    for r in range(120):
+        q0 = np.empty((2, 17))
+        for c in range(2):
+            m.ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
+            q0[c] = m.ravel(pt) + 0.1 * np.random.default_rng([1, c]).uniform(-1, 1, 17)
+        smp = m.ctx.sampler([0, 1], q0, tune=20, seed=1)
+        th, _ = smp.run(28)
+        smp.close()
+        if ref is None:
+            ref = th
+        else:
+            assert np.array_equal(th, ref), r
+    m.close()

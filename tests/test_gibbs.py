@@ -220,3 +220,31 @@ def test_gpu_sweep_streams_are_keyed_by_chain_slot():
             i_gpu, w_gpu = ctx.get_discrete(c)
             np.testing.assert_array_equal(i_gpu, refs[c][0])
             np.testing.assert_array_equal(w_gpu, refs[c][1])
+
+
+@gpu
+@pytest.mark.parametrize("dense", [True, False])
+def test_gpu_sweep_fp32_storage(dense):
+    """fp32-held panels / lists: the sweep equals the CPU restatement run on the fp32-rounded data."""
+    if dense:
+        coh = oracle_cohort_from_synth(synthetic.make_cohort(70, 90, seed=12))
+    else:
+        from tests.helpers import random_sparse_cohort
+
+        coh = random_sparse_cohort(40, 30, 900, 800, seed=13)
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    coh32 = O.Cohort(coh.n_gaps, coh.n_inds, coh.vacs, coh.pcrpos,
+                     O.AntigenObs(coh.s.idx_gap, coh.s.idx_ind, r32(coh.s.log_dilution), r32(coh.s.od)),
+                     O.AntigenObs(coh.n.idx_gap, coh.n.idx_ind, r32(coh.n.log_dilution), r32(coh.n.od)))
+    co = c_oracle.COracle(coh32, (20,))
+    ctx = _ctx(coh, (20,), n_chains=1, storage="f32")
+    assert ctx.is_dense == dense
+    theta, i_raw, w = _state(coh, 77)
+    ctx.set_discrete(0, i_raw, w)
+    for sweep in range(2):
+        acc, prop = ctx.gibbs_sweep([0], theta[None], seed=31, sweep=sweep)
+        i_raw, w, a_ref, p_ref = co.gibbs_sweep(theta, i_raw, w, chain=0, seed=31, sweep=sweep)
+        i_gpu, w_gpu = ctx.get_discrete(0)
+        np.testing.assert_array_equal(i_gpu, i_raw)
+        np.testing.assert_array_equal(w_gpu, w)
+        assert (int(acc[0]), int(prop[0])) == (a_ref, p_ref)

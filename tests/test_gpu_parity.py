@@ -216,6 +216,28 @@ def test_fp32_storage():
     assert abs(lp - lp64) <= 1e-4 * abs(lp64)
 
 
+@pytest.mark.parametrize("lanes", ["1", "0"])
+def test_fp32_storage_sparse_lists(lanes, monkeypatch):
+    """fp32-held observation lists through both sparse kernels (logp + gradient and the logp-only form)."""
+    monkeypatch.setenv("ABD_OBS_LANES", lanes)
+    coh = random_sparse_cohort(50, 40, 1500, 1300, seed=3)
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    coh32 = O.Cohort(
+        coh.n_gaps, coh.n_inds, coh.vacs, coh.pcrpos,
+        O.AntigenObs(coh.s.idx_gap, coh.s.idx_ind, r32(coh.s.log_dilution), r32(coh.s.od)),
+        O.AntigenObs(coh.n.idx_gap, coh.n.idx_ind, r32(coh.n.log_dilution), r32(coh.n.od)),
+    )
+    ctx = _ctx(coh, (13, 27), n_chains=2, storage="f32")
+    assert not ctx.is_dense
+    for c in range(2):
+        theta, i_raw, w = _state(coh, 60 + c)
+        ctx.set_discrete(c, i_raw, w)
+        lp, g = ctx.logp_dlogp(c, theta)
+        lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh32, (13, 27))
+        assert_close(lp, g, lp_ref, g_ref)
+        assert abs(ctx.logp(c, theta) - lp_ref) <= RTOL * abs(lp_ref)
+
+
 def test_flip_discrete_matches_reupload():
     coh = oracle_cohort_from_synth(synthetic.make_cohort(33, 40, seed=25))
     ctx = _ctx(coh, (20,))

@@ -160,10 +160,11 @@ def test_gpu_sweep_matches_cpu_restatement_dense(G, N, splits):
 
 @gpu
 @pytest.mark.parametrize("ignore", [False, True])
-def test_gpu_sweep_matches_cpu_restatement_sparse(ignore):
-    coh = random_sparse_cohort(41, 26, 900, 700, seed=5)
-    co = c_oracle.COracle(coh, (10,), ignore)
-    ctx = _ctx(coh, (10,), ignore)
+@pytest.mark.parametrize("N,G,ks,kn,splits", [(41, 26, 900, 700, (10,)), (12, 200, 2500, 2100, (66, 133)), (30, 70, 40, 0, None)])
+def test_gpu_sweep_matches_cpu_restatement_sparse(ignore, N, G, ks, kn, splits):
+    coh = random_sparse_cohort(N, G, ks, kn, seed=5)
+    co = c_oracle.COracle(coh, splits, ignore)
+    ctx = _ctx(coh, splits, ignore)
     theta, i_raw, w = _state(coh, 6)
     ctx.set_discrete(0, i_raw, w)
     for sweep in range(2):

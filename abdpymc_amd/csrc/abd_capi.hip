@@ -93,14 +93,23 @@ struct abd_ctx {
   uint64_t* pw = nullptr;  // [nt][N]
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
-  double* partials[2] = {nullptr, nullptr};  // [n_slots][blocks_max][ABD_NOUT], alternating per launch
-  int pbuf = 0;
-  struct {
-    bool on = false;  // the fixed-order sum of this launch's partials has not been queued yet
+  // A pipe = a HIP stream with its own pair of partial buffers and its own pending fixed-order sum.  Pipe 0 is
+  // the context's stream (everything synchronous runs there).  Stream-ordered dense launches alternate between
+  // pipe 0 and pipe 1: launch k+2 sums launch k's partials (same pipe), so the two streams never wait for each
+  // other and the head of one launch overlaps the tail of the previous one.
+  struct Pipe {
+    hipStream_t st = nullptr;
+    double* partials[2] = {nullptr, nullptr};  // [n_slots][blocks_max][ABD_NOUT], alternating per launch
+    int pbuf = 0;
+    bool on = false;  // pending: the fixed-order sum of the last launch's partials has not been queued yet
     int buf = 0, n = 0, blocks = 0;
     double* out = nullptr;
     double tag = 0.0;
-  } pending;
+    bool busy = false;  // pipe 1: work queued since the last join with pipe 0
+  } pipe[2];
+  bool two_pipes = true;
+  int next_pipe = 0;
+  hipEvent_t join_ev = nullptr;
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
   bool xcd_remap = true;
@@ -373,18 +382,38 @@ int dense_blocks(const abd_ctx* c, int cpw) {
 }
 
 // queue the standalone fixed-order sum of a launch whose partials are still pending
-int flush_pending(abd_ctx* c) {
-  if (c->pending.on) {
-    hipLaunchKernelGGL(abd_finalize_kernel, dim3(c->pending.n), dim3(ABD_FIN_THREADS), 0, c->stream,
-                       c->partials[c->pending.buf], c->pending.blocks, c->pending.out, c->pending.tag);
+int flush_pipe(abd_ctx* c, int pi) {
+  abd_ctx::Pipe& p = c->pipe[pi];
+  if (p.on) {
+    hipLaunchKernelGGL(abd_finalize_kernel, dim3(p.n), dim3(ABD_FIN_THREADS), 0, p.st, p.partials[p.buf], p.blocks, p.out, p.tag);
     HIP_TRY(hipGetLastError());
-    c->pending.on = false;
+    p.on = false;
   }
   return ABD_OK;
 }
 
+// pipe 0 continues only after everything queued on pipe 1 has finished
+int join_pipes(abd_ctx* c) {
+  abd_ctx::Pipe& p1 = c->pipe[1];
+  if (!p1.st) return ABD_OK;
+  if (int rc = flush_pipe(c, 1)) return rc;
+  if (p1.busy) {
+    HIP_TRY(hipEventRecord(c->join_ev, p1.st));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
+    p1.busy = false;
+  }
+  c->next_pipe = 0;
+  return ABD_OK;
+}
+
+int flush_pending(abd_ctx* c) {
+  if (int rc = flush_pipe(c, 0)) return rc;
+  return join_pipes(c);
+}
+
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
-int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows) {
+int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
+                  bool deferred = false) {
   EvalArgs a;
   base_args(c, a);
   a.n_chains = n;
@@ -405,21 +434,31 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
   dim3 grid(blocks, n / cpw);
-  const int buf = c->pbuf;
-  c->pbuf ^= 1;
-  a.partials = c->partials[buf];
+  // stream-ordered dense launches alternate between the two pipes; everything else runs on pipe 0 after a join
+  int pi = 0;
+  if (deferred && c->two_pipes && c->pipe[1].st && c->fuse_finalize && !c->timing) {  // timing: one launch at a time
+    pi = c->next_pipe;
+    c->next_pipe ^= 1;
+  } else if (int jrc = join_pipes(c)) {
+    return jrc;
+  }
+  abd_ctx::Pipe& pp = c->pipe[pi];
+  if (pi == 1) pp.busy = true;
+  const int buf = pp.pbuf;
+  pp.pbuf ^= 1;
+  a.partials = pp.partials[buf];
   a.fin_rows = c->fin_rows;
   a.xcd_remap = c->xcd_remap ? 1 : 0;
-  if (c->dense && c->fuse_finalize && c->pending.on && c->pending.n <= blocks) {
-    // this launch's first workgroups sum the previous launch's partials
-    a.prev_partials = c->partials[c->pending.buf];
-    a.prev_out = c->pending.out;
-    a.prev_n_chains = c->pending.n;
-    a.prev_blocks = c->pending.blocks;
-    a.prev_tag = c->pending.tag;
-    c->pending.on = false;
+  if (c->dense && c->fuse_finalize && pp.on && pp.n <= blocks) {
+    // this launch's first workgroups sum the partials of the previous launch on the same pipe
+    a.prev_partials = pp.partials[pp.buf];
+    a.prev_out = pp.out;
+    a.prev_n_chains = pp.n;
+    a.prev_blocks = pp.blocks;
+    a.prev_tag = pp.tag;
+    pp.on = false;
   } else {
-    int frc = flush_pending(c);
+    int frc = flush_pipe(c, pi);
     if (frc) return frc;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -433,28 +472,28 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     e0 = c->ev_pool[c->ev_used].first;
     e1 = c->ev_pool[c->ev_used].second;
     c->ev_used++;
-    HIP_TRY(hipEventRecord(e0, c->stream));
+    HIP_TRY(hipEventRecord(e0, pp.st));
   }
   hipError_t le;
   if (lanes)
-    le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, c->stream, a)
-                                     : launch_obs<double>(grad, grid, lds, c->stream, a);
+    le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, pp.st, a)
+                                     : launch_obs<double>(grad, grid, lds, pp.st, a);
   else if (c->dense)
-    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, c->stream, a)
-                                     : launch_dense<double>(cpw, grad, grid, lds, c->stream, a);
+    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, pp.st, a)
+                                     : launch_dense<double>(cpw, grad, grid, lds, pp.st, a);
   else
-    le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, c->stream, a)
-                                     : launch_sparse<double>(cpw, grad, grid, lds, c->stream, a);
-  if (c->timing) HIP_TRY(hipEventRecord(e1, c->stream));
+    le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, pp.st, a)
+                                     : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);
+  if (c->timing) HIP_TRY(hipEventRecord(e1, pp.st));
   HIP_TRY(le);
-  c->pending.on = true;
-  c->pending.buf = buf;
-  c->pending.n = n;
-  c->pending.blocks = blocks;
-  c->pending.out = d_out_rows;
+  pp.on = true;
+  pp.buf = buf;
+  pp.n = n;
+  pp.blocks = blocks;
+  pp.out = d_out_rows;
   c->seq += 1.0;
-  c->pending.tag = c->seq;
-  if (!(c->dense && c->fuse_finalize)) return flush_pending(c);
+  pp.tag = c->seq;
+  if (!(c->dense && c->fuse_finalize)) return flush_pipe(c, pi);
   return ABD_OK;
 }
 
@@ -527,7 +566,7 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   }
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
-    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT);
+    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred);
     if (rc) return rc;
   }
   return ABD_OK;
@@ -647,8 +686,12 @@ void free_ctx(abd_ctx* c) {
     if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
   }
-  for (int b = 0; b < 2; ++b)
-    if (c->partials[b]) (void)hipFree(c->partials[b]);
+  if (c->pipe[1].st) (void)hipStreamSynchronize(c->pipe[1].st);
+  for (int pi = 0; pi < 2; ++pi)
+    for (int b = 0; b < 2; ++b)
+      if (c->pipe[pi].partials[b]) (void)hipFree(c->pipe[pi].partials[b]);
+  if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+  if (c->pipe[1].st) (void)hipStreamDestroy(c->pipe[1].st);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
@@ -793,7 +836,16 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     CREATE_TRY(hipMalloc(&s.rw, words * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
   }
-  for (int b = 0; b < 2; ++b) CREATE_TRY(hipMalloc(&c->partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
+  c->pipe[0].st = c->stream;
+  if (const char* e = std::getenv("ABD_TWO_PIPES")) c->two_pipes = std::atoi(e) != 0;
+  if (c->two_pipes && c->dense) {
+    CREATE_TRY(hipStreamCreateWithFlags(&c->pipe[1].st, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming));
+  }
+  for (int pi = 0; pi < 2; ++pi)
+    if (c->pipe[pi].st)
+      for (int b = 0; b < 2; ++b)
+        CREATE_TRY(hipMalloc(&c->pipe[pi].partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
   if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_XCD_REMAP")) c->xcd_remap = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
@@ -837,6 +889,7 @@ int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_
   HIP_TRY(hipSetDevice(c->device));
   ChainSlot& s = c->slots[(size_t)chain];
   // synchronous copies: the caller's buffers may be reused immediately
+  if (int jrc = join_pipes(c)) return jrc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpy(c->stage_gn, i_raw, cells, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(s.waner, waner, (size_t)c->N, hipMemcpyHostToDevice));
@@ -855,6 +908,7 @@ int abd_flip_discrete(abd_ctx* c, int32_t chain, int64_t flat) {
   if (flat < 0 || flat >= total) return fail(ABD_ERR_ARG, "flat index %lld outside [0, %lld)", (long long)flat, (long long)total);
   if (!c->slots[(size_t)chain].set) return fail(ABD_ERR_STATE, "chain slot %d has no discrete state", chain);
   HIP_TRY(hipSetDevice(c->device));
+  if (int jrc = join_pipes(c)) return jrc;
   ChainSlot& s = c->slots[(size_t)chain];
   hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, s.rw, s.waner, c->G, c->N, flat);
   HIP_TRY(hipGetLastError());
@@ -934,6 +988,7 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   int rc = check_chains(c, 1, &chain);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  if (int jrc = join_pipes(c)) return jrc;
   const size_t cells = (size_t)c->G * c->N;
   if (!c->d_det) HIP_TRY(hipMalloc(&c->d_det, cells * (2 * sizeof(double) + 1)));  // staging, kept for the next draw
   double* d_n = c->d_det;
@@ -1023,6 +1078,7 @@ int abd_get_discrete(abd_ctx* c, int32_t chain, int8_t* i_raw, int8_t* waner) {
   int rc = check_chains(c, 1, &chain);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  if (int jrc = join_pipes(c)) return jrc;
   ChainSlot& s = c->slots[(size_t)chain];
   if (i_raw) {
     dim3 grid((c->N + 255) / 256, c->G);
@@ -1060,6 +1116,7 @@ int abd_kernel_timing(abd_ctx* c, int32_t enable) {
 int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t reset) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
+  if (int jrc = join_pipes(c)) return jrc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (size_t k = 0; k < c->ev_used; ++k) {
     float ms = 0.f;

@@ -128,6 +128,8 @@ int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const d
 /* Stream-ordered form: enqueue returns as soon as the launch is queued; results land in result slot
  * `slot` (0 <= slot < abd_n_result_slots) and are read back with abd_fetch after abd_wait.
  * A NUTS driver that runs several chain groups uses this to overlap host work with the device.
+ * Dense cohorts: consecutive enqueued launches go to two HIP streams in turn (launch k+2 sums launch k's
+ * partials), so they overlap instead of draining the chip between launches; abd_wait joins both.
  * Synchronous calls may be interleaved: they use rows of their own and leave every result slot alone;
  * both forms return identical bits for the same (chains, theta). */
 int abd_n_result_slots(abd_ctx* ctx);
@@ -197,8 +199,10 @@ int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu
 int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric);
 
 /* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
- * events on the context's stream; abd_kernel_time returns the accumulated kernel time and launch count
- * since the last reset (synchronises the stream). */
+ * events on the stream it is launched on, and stream-ordered launches all go to ONE stream (normally they
+ * alternate between two, so that the head of a launch overlaps the tail of the previous one: a launch's
+ * own duration is only meaningful when nothing else is in flight).  abd_kernel_time returns the accumulated
+ * kernel time and launch count since the last reset (synchronises). */
 int abd_kernel_timing(abd_ctx* ctx, int32_t enable);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 

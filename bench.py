@@ -127,6 +127,18 @@ def main():
     # ---- timed region: EXACTLY K steps ----
     lp_all = np.empty((K, C))
     g_all = np.empty((K, C, 17))
+    if dist is not None:
+        # RCCL builds its communicator and buffers on first use: not part of a step
+        from abdpymc_amd.distributed import gather_samples
+
+        gather_samples(np.zeros((K, C, 18)), dist, device="cuda")
+    # The first barrier absorbs the collective's start-up; the part idles meanwhile and a few ms of idling cost
+    # ~2.5 ms of ramp-up afterwards (tools/probe_idle_penalty.py), so: barrier, warm up again, then the barrier
+    # that opens the timed region (a fraction of a millisecond by now).
+    barrier()
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.015:
+        run_steps(0, max(W, 8) if W + K >= 8 else W + K)
     barrier()
     t0 = time.perf_counter()
     run_steps(W, W + K, lp_all, g_all)
@@ -136,8 +148,11 @@ def main():
 
         gathered = gather_samples(np.concatenate([lp_all[..., None], g_all], axis=-1), dist, device="cuda")
         assert gathered.shape == (world, K, C, 18)
+    t_steps = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("ABD_BENCH_DEBUG"):
+        print(f"[bench debug] steps+gather {t_steps * 1e3:.3f} ms, closing barrier {(elapsed - t_steps) * 1e3:.3f} ms", file=sys.stderr)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -192,17 +192,14 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
         // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
         const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
         const double as = fma(cf_s, perm_s, init_s) + ts;
-        double h = 0.0;
-        obs_term<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, guard, acc[A_N_Q2], acc[A_N_H], acc[A_N_HX], acc[A_N_QS], h);
+        double h_n = 0.0, h_s = 0.0;
+        obs_pair<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, as, (double)os.x, (double)os.y, b_s, d_s, guard, acc, h_n, h_s);
         if (GRAD) {
-          acc[A_N_HC] = fma(h, cf_n, acc[A_N_HC]);
-          acc[A_N_HU] = fma(h, tn, acc[A_N_HU]);
-          acc[A_N_HD] = fma(h, dn, acc[A_N_HD]);
-        }
-        obs_term<GRAD>(as, (double)os.x, (double)os.y, b_s, d_s, guard, acc[A_S_Q2], acc[A_S_H], acc[A_S_HX], acc[A_S_QS], h);
-        if (GRAD) {
-          acc[A_S_HC] = fma(h, cf_s, acc[A_S_HC]);
-          hd_s = fma(h, ds, hd_s);
+          acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
+          acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
+          acc[A_N_HD] = fma(h_n, dn, acc[A_N_HD]);
+          acc[A_S_HC] = fma(h_s, cf_s, acc[A_S_HC]);
+          hd_s = fma(h_s, ds, hd_s);
         }
       };
 

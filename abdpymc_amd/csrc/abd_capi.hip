@@ -106,10 +106,11 @@ struct abd_ctx {
     double* out = nullptr;
     double tag = 0.0;
     bool busy = false;  // pipe 1: work queued since the last join with pipe 0
-  } pipe[2];
-  bool two_pipes = true;
+  } pipe[4];
+  int n_pipes = 3;        // streams that stream-ordered dense launches rotate over (1 = everything on the context's stream)
+  int pipe_blocks = 0;    // dense grid of a launch that shares the chip with n_pipes - 1 others
   int next_pipe = 0;
-  hipEvent_t join_ev = nullptr;
+  hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
   bool xcd_remap = true;
@@ -374,11 +375,11 @@ int pick_cpw(const abd_ctx* c, int n) {
 
 // grid of the dense kernel: an exact multiple of the CU count (every wave slot gets the same number of
 // gap rows), capped so a slot has at least kMinRows rows
-int dense_blocks(const abd_ctx* c, int cpw) {
+int dense_blocks(const abd_ctx* c, int cpw, bool shared = false) {
   const int nsub = ABD_WAVES_PER_BLOCK / cpw;
   const int64_t rows = (int64_t)c->n_lg * c->G;
   const int64_t cap = std::max<int64_t>(1, rows / ((int64_t)kMinRows * nsub));
-  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)c->dense_blocks, cap, (int64_t)c->blocks_max}));
+  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(shared ? c->pipe_blocks : c->dense_blocks), cap, (int64_t)c->blocks_max}));
 }
 
 // queue the standalone fixed-order sum of a launch whose partials are still pending
@@ -394,13 +395,15 @@ int flush_pipe(abd_ctx* c, int pi) {
 
 // pipe 0 continues only after everything queued on pipe 1 has finished
 int join_pipes(abd_ctx* c) {
-  abd_ctx::Pipe& p1 = c->pipe[1];
-  if (!p1.st) return ABD_OK;
-  if (int rc = flush_pipe(c, 1)) return rc;
-  if (p1.busy) {
-    HIP_TRY(hipEventRecord(c->join_ev, p1.st));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
-    p1.busy = false;
+  for (int pi = 1; pi < c->n_pipes; ++pi) {
+    abd_ctx::Pipe& p = c->pipe[pi];
+    if (!p.st) continue;
+    if (int rc = flush_pipe(c, pi)) return rc;
+    if (p.busy) {
+      HIP_TRY(hipEventRecord(c->join_ev[pi], p.st));
+      HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev[pi], 0));
+      p.busy = false;
+    }
   }
   c->next_pipe = 0;
   return ABD_OK;
@@ -420,13 +423,15 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
   const bool lanes = !c->dense && c->obs_lanes;
   const int cpw = lanes ? 1 : pick_cpw(c, n);
+  // stream-ordered dense launches rotate over the pipes; everything else runs on pipe 0 after a join
+  const bool rotate = deferred && c->n_pipes > 1 && c->dense && c->fuse_finalize && !c->timing;  // timing: one launch at a time
   int blocks;
   size_t lds;
   if (lanes) {
     blocks = c->ob_n + c->ob_s + c->ob_c;
     lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
   } else if (c->dense) {
-    blocks = dense_blocks(c, cpw);
+    blocks = dense_blocks(c, cpw, rotate);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
   } else {
     blocks = c->blocks_x;
@@ -434,16 +439,15 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
   dim3 grid(blocks, n / cpw);
-  // stream-ordered dense launches alternate between the two pipes; everything else runs on pipe 0 after a join
   int pi = 0;
-  if (deferred && c->two_pipes && c->pipe[1].st && c->fuse_finalize && !c->timing) {  // timing: one launch at a time
+  if (rotate) {
     pi = c->next_pipe;
-    c->next_pipe ^= 1;
+    c->next_pipe = (c->next_pipe + 1) % c->n_pipes;
   } else if (int jrc = join_pipes(c)) {
     return jrc;
   }
   abd_ctx::Pipe& pp = c->pipe[pi];
-  if (pi == 1) pp.busy = true;
+  if (pi > 0) pp.busy = true;
   const int buf = pp.pbuf;
   pp.pbuf ^= 1;
   a.partials = pp.partials[buf];
@@ -686,12 +690,15 @@ void free_ctx(abd_ctx* c) {
     if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
   }
-  if (c->pipe[1].st) (void)hipStreamSynchronize(c->pipe[1].st);
-  for (int pi = 0; pi < 2; ++pi)
+  for (int pi = 1; pi < 4; ++pi)
+    if (c->pipe[pi].st) (void)hipStreamSynchronize(c->pipe[pi].st);
+  for (int pi = 0; pi < 4; ++pi)
     for (int b = 0; b < 2; ++b)
       if (c->pipe[pi].partials[b]) (void)hipFree(c->pipe[pi].partials[b]);
-  if (c->join_ev) (void)hipEventDestroy(c->join_ev);
-  if (c->pipe[1].st) (void)hipStreamDestroy(c->pipe[1].st);
+  for (int pi = 1; pi < 4; ++pi) {
+    if (c->join_ev[pi]) (void)hipEventDestroy(c->join_ev[pi]);
+    if (c->pipe[pi].st) (void)hipStreamDestroy(c->pipe[pi].st);
+  }
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
@@ -837,12 +844,19 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
   }
   c->pipe[0].st = c->stream;
-  if (const char* e = std::getenv("ABD_TWO_PIPES")) c->two_pipes = std::atoi(e) != 0;
-  if (c->two_pipes && c->dense) {
-    CREATE_TRY(hipStreamCreateWithFlags(&c->pipe[1].st, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming));
+  if (const char* e = std::getenv("ABD_TWO_PIPES")) c->n_pipes = std::atoi(e) != 0 ? 2 : 1;
+  if (const char* e = std::getenv("ABD_PIPES")) c->n_pipes = std::max(1, std::min(4, std::atoi(e)));
+  if (!c->dense) c->n_pipes = 1;
+  for (int pi = 1; pi < c->n_pipes; ++pi) {
+    CREATE_TRY(hipStreamCreateWithFlags(&c->pipe[pi].st, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&c->join_ev[pi], hipEventDisableTiming));
   }
-  for (int pi = 0; pi < 2; ++pi)
+  // a launch that shares the chip with the other pipes' launches gets 1/n_pipes of the workgroup slots: fewer,
+  // longer ranges, i.e. less per-range set-up for the same work
+  c->pipe_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, dbpc / c->n_pipes));  // measured best: 3 pipes x 1 workgroup per CU
+  if (const char* e = std::getenv("ABD_PIPE_BLOCKS_PER_CU")) c->pipe_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
+  if (const char* e = std::getenv("ABD_PIPE_BLOCKS")) c->pipe_blocks = std::max(1, std::min(std::atoi(e), c->blocks_max));
+  for (int pi = 0; pi < 4; ++pi)
     if (c->pipe[pi].st)
       for (int b = 0; b < 2; ++b)
         CREATE_TRY(hipMalloc(&c->pipe[pi].partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));

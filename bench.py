@@ -9,8 +9,8 @@ read once per launch).  For N>1 GPUs every rank holds its own 4 chains (config 4
 weak scaling, no data-path collective) and the (steps x chains x 18) sample block is gathered over RCCL
 once at the end of the timed region.
 
-Timed region: K steps enqueued stream-ordered (the library alternates two HIP streams so that the head of a
-launch overlaps the tail of the previous one), one wait, results fetched (host-side prior terms included),
+Timed region: K steps enqueued stream-ordered (the library rotates them over three HIP streams so that
+launches share the chip instead of draining it one after the other), one wait, results fetched (host-side prior terms included),
 bracketed by barrier + device sync.  Inputs are resident in HBM before it starts.  Warm-up: W untimed steps
 as asked, repeated until at least 60 ms have passed -- after an idle period the part needs ~3 ms of load to
 reach its sustained state, which 20 steps (0.6 ms) do not cover.

@@ -128,10 +128,11 @@ int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const d
 /* Stream-ordered form: enqueue returns as soon as the launch is queued; results land in result slot
  * `slot` (0 <= slot < abd_n_result_slots) and are read back with abd_fetch after abd_wait.
  * A NUTS driver that runs several chain groups uses this to overlap host work with the device.
- * Dense cohorts: consecutive enqueued launches go to two HIP streams in turn (launch k+2 sums launch k's
- * partials), so they overlap instead of draining the chip between launches; abd_wait joins both.
- * Synchronous calls may be interleaved: they use rows of their own and leave every result slot alone;
- * both forms return identical bits for the same (chains, theta). */
+ * Dense cohorts: consecutive enqueued launches rotate over three HIP streams (launch k+3 sums launch k's
+ * partials), each with a quarter of the workgroups of a synchronous launch, so three share the chip instead
+ * of one draining it between launches; abd_wait joins them.
+ * Synchronous calls may be interleaved: they use rows of their own and leave every result slot alone.
+ * Each form is bit-reproducible; the two forms use different launch shapes and agree to rounding (~1e-15). */
 int abd_n_result_slots(abd_ctx* ctx);
 int abd_logp_dlogp_batch_enqueue(abd_ctx* ctx, int32_t slot, int32_t n, const int32_t* chains,
                                  const double* theta);

@@ -105,10 +105,10 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     const int g0 = (int)(pos - (int64_t)lg * G);
     const int g1 = (int)min((int64_t)G, (int64_t)g0 + (end - pos));
     pos += g1 - g0;
-    const int j_raw = lg * 64 + lane;
-    const bool active = j_raw < N;
-    const int j = active ? j_raw : N - 1;
-    const double guard = active ? 1.0 : 0.0;
+    // lanes past the last individual (only the last lane group has any) sit the piece out: EXEC masks them, so
+    // they neither load nor contribute and the residuals need no 0/1 guard factor
+    const int j = lg * 64 + lane;
+    if (j < N) {
 
     // packed indicator rows of this lane's individual; constrain (abd.py:640-667)
     uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     }
     const bool wj = p.waner[j] != 0;
     constrain_masks(Rw, P, a, I);
-    if (g0 == 0 && active) {  // each individual's gap 0 belongs to exactly one piece
+    if (g0 == 0) {  // each individual's gap 0 belongs to exactly one piece
       int n1 = 0;
 #pragma unroll
       for (int t = 0; t < ABD_MAXT; ++t) n1 += __builtin_popcountll(Rw[t]);  // Bernoulli(i_raw | p) is on the RAW matrix
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
         const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
         const double as = fma(cf_s, perm_s, init_s) + ts;
         double h_n = 0.0, h_s = 0.0;
-        obs_pair<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, as, (double)os.x, (double)os.y, b_s, d_s, guard, acc, h_n, h_s);
+        obs_pair<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, as, (double)os.x, (double)os.y, b_s, d_s, acc, h_n, h_s);
         if (GRAD) {
           acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
           acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
       if (gi < len) step(n0, s0);
     }
     acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
+    }  // j < N
   }
 
   // ---- reduction: lanes -> wave -> block (LDS) -> per-block partial in global memory ----

@@ -344,15 +344,14 @@ __device__ __forceinline__ void obs_term(double a, double x, double y, double b,
 // cell.  The exponents are clamped at 2^510 so that the product stays finite (the curve is ~1e-154 of d there).
 template <bool GRAD>
 __device__ __forceinline__ void obs_pair(double an, double xn, double yn, double b_n, double d_n, double as, double xs,
-                                         double ys, double b_s, double d_s, double guard, double (&acc)[16], double& h_n,
-                                         double& h_s) {
+                                         double ys, double b_s, double d_s, double (&acc)[16], double& h_n, double& h_s) {
   const double amx_n = an - xn, amx_s = as - xs;
   const double e_n = exp2_reduced(fmin((b_n * 1.4426950408889634074) * amx_n, 510.0));
   const double e_s = exp2_reduced(fmin((b_s * 1.4426950408889634074) * amx_s, 510.0));
   const double A = 1.0 + e_n, B = 1.0 + e_s;
   const double r = rcp_newton(A * B);
   const double s_n = r * B, s_s = r * A;  // logistic / d
-  const double q_n = fma(-d_n, s_n, yn) * guard, q_s = fma(-d_s, s_s, ys) * guard;
+  const double q_n = fma(-d_n, s_n, yn), q_s = fma(-d_s, s_s, ys);
   acc[A_N_Q2] = fma(q_n, q_n, acc[A_N_Q2]);
   acc[A_S_Q2] = fma(q_s, q_s, acc[A_S_Q2]);
   if (GRAD) {

@@ -159,39 +159,93 @@ __device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& 
   }
 }
 
-// Sparse lists: lanes over the individual's observations; everything in one per-lane sum.
+// Sparse lists: the individual's observations of BOTH antigens form one combined list (N first, then S), 64 per
+// pass, one per lane.  The first pass -- the only one for the reference's cohorts (~12 + 12 observations per
+// individual) -- is kept in registers for the whole sweep together with the lane's antigen-specific constants, so
+// a proposal costs one response + one logistic term per lane and no memory traffic.
+template <typename R>
+struct ObsLane {
+  int g;              // gap of the observation
+  double y, x;        // od, log dilution
+  double guard;       // 1 for a real observation, 0 for a padding lane
+  bool is_s;          // S antigen (else N)
+  double init, perm, temp, b, d, nh_is2;  // the antigen's constants: a = init + [exposed] perm + temp u ; -1/2 sigma^-2
+};
+
+template <typename R>
+__device__ __forceinline__ ObsLane<R> load_obs_lane(const EvalArgs& a, const ChainPar& p, int j, int idx, double is2_n,
+                                                    double is2_s) {
+  ObsLane<R> o;
+  const int kn0 = a.ptr_n[j], cnt_n = a.ptr_n[j + 1] - kn0;
+  const int ks0 = a.ptr_s[j], cnt_s = a.ptr_s[j + 1] - ks0;
+  o.is_s = idx >= cnt_n;
+  const bool valid = idx < cnt_n + cnt_s;
+  o.guard = valid ? 1.0 : 0.0;
+  o.g = 0;
+  o.y = o.x = 0.0;
+  if (valid) {
+    if (o.is_s) {
+      const int k = ks0 + idx - cnt_n;
+      o.g = a.g_s[k];
+      o.y = ld<R>(a.y_s, k);
+      o.x = ld<R>(a.x_s, k);
+    } else {
+      const int k = kn0 + idx;
+      o.g = a.g_n[k];
+      o.y = ld<R>(a.y_n, k);
+      o.x = ld<R>(a.x_n, k);
+    }
+  }
+  o.init = o.is_s ? p.init_s : p.init_n;
+  o.perm = o.is_s ? p.perm_s : p.perm_n;
+  o.temp = o.is_s ? 1.0 : p.temp_n;  // unit S boosts (Q1)
+  o.b = o.is_s ? p.b_s : p.b_n;
+  o.d = o.is_s ? p.d_s : p.d_n;
+  o.nh_is2 = -0.5 * (o.is_s ? is2_s : is2_n);
+  return o;
+}
+
+template <typename R>
+__device__ __forceinline__ double obs_lane_term(const EvalArgs& a, const ObsLane<R>& o, const uint64_t I[ABD_MAXT],
+                                                const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s) {
+  const double2_t* tb = o.is_s ? tab_s : tab_n;
+  double u = 0.0;
+  bool cum = false;
+#pragma unroll
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    if (t < a.nt) {
+      const int rel = o.g - t * 64;  // bits <= rel of word t are exposures at or before the observation's gap
+      const uint64_t le = rel >= 63 ? ~0ull : (rel < 0 ? 0ull : ((2ull << rel) - 1ull));
+      cum |= ((o.is_s ? (I[t] | V[t]) : I[t]) & le) != 0;
+      uint64_t m = I[t];
+      while (m) {  // wave-uniform loops over the set bits; table entry 0 is "in the future" = 0
+        const int bpos = __builtin_ctzll(m);
+        m &= m - 1;
+        u += tb[max(rel - bpos + 1, 0)].x;
+      }
+      m = V[t];
+      while (m) {
+        const int bpos = __builtin_ctzll(m);
+        m &= m - 1;
+        const double v = tb[max(rel - bpos + 1, 0)].x;
+        u += o.is_s ? v : 0.0;  // doses boost S only
+      }
+    }
+  }
+  const double resp = o.init + (cum ? o.perm : 0.0) + o.temp * u;
+  double q2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+  obs_term<false>(resp, o.x, o.y, o.b, o.d, o.guard, q2, d0, d1, d2, d3);
+  return o.nh_is2 * q2;
+}
+
 template <typename R>
 __device__ __forceinline__ double sparse_terms(const EvalArgs& a, const ChainPar& p, int j, int lane, const uint64_t I[ABD_MAXT],
                                                const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
-                                               double is2_n, double is2_s) {
-  double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;  // unused gradient outputs
-  double acc = 0.0;
-#pragma unroll
-  for (int ag = 0; ag < 2; ++ag) {
-    const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
-    const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
-    const void* yy = ag == 0 ? a.y_n : a.y_s;
-    const void* xx = ag == 0 ? a.x_n : a.x_s;
-    const int k0 = ptr[j], k1 = ptr[j + 1];
-    for (int kb = k0; kb < k1; kb += 64) {
-      const int k = kb + lane;
-      const bool in = k < k1;
-      const int kk = in ? k : k0;
-      const int g = gi[kk];
-      const double y = ld<R>(yy, kk), x = ld<R>(xx, kk);
-      const Resp rs = responses(g, a.nt, I, V, tab_n, tab_s);
-      const double guard = in ? 1.0 : 0.0;
-      double q2 = 0.0;
-      if (ag == 0) {
-        const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
-        obs_term<false>(an, x, y, p.b_n, p.d_n, guard, q2, d0, d1, d2, d3);
-        acc = fma(-0.5 * is2_n, q2, acc);
-      } else {
-        const double as = p.init_s + (rs.cum_iv ? p.perm_s : 0.0) + rs.us;
-        obs_term<false>(as, x, y, p.b_s, p.d_s, guard, q2, d0, d1, d2, d3);
-        acc = fma(-0.5 * is2_s, q2, acc);
-      }
-    }
+                                               double is2_n, double is2_s, const ObsLane<R>& first, int n_obs) {
+  double acc = obs_lane_term<R>(a, first, I, V, tab_n, tab_s);
+  for (int base = 64; base < n_obs; base += 64) {  // individuals with more than 64 observations: the rest from memory
+    const ObsLane<R> o = load_obs_lane<R>(a, p, j, base + lane, is2_n, is2_s);
+    acc += obs_lane_term<R>(a, o, I, V, tab_n, tab_s);
   }
   return acc;
 }
@@ -268,6 +322,14 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     }
     __builtin_amdgcn_wave_barrier();
 
+    // sparse lists: this lane's observation of the first pass and the individual's observation count
+    ObsLane<R> first;
+    int n_obs = 0;
+    if (!DENSE) {
+      first = load_obs_lane<R>(a, p, j, lane, is2_n, is2_s);
+      n_obs = __builtin_amdgcn_readfirstlane((a.ptr_n[j + 1] - a.ptr_n[j]) + (a.ptr_s[j + 1] - a.ptr_s[j]));
+    }
+
     // this lane's terms at the current state (dense: by round of 64 gaps, with the responses carried into
     // each round; sparse: one sum in cur[0])
     double cur[ABD_MAXT], cur_cn = 0.0, cur_cs = 0.0;
@@ -290,7 +352,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
                              0, cur_cn, cur_cs, cur, cur, 0.0, 0.0, unused_delta, unused_dead);
       refresh_bounds();
     } else {
-      cur[0] = sparse_terms<R>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s);
+      cur[0] = sparse_terms<R>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
     }
 
     // ---- the sweep ----
@@ -336,7 +398,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
           dense_rounds<R, true>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn,
                                 ds, r0, nxt_cn, nxt_cs, nxt, cur, suf, log_u, delta, dead);
         } else {
-          nxt[0] = sparse_terms<R>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s);
+          nxt[0] = sparse_terms<R>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
           delta += wave_sum_uniform(nxt[0] - cur[0]);
         }
       }

@@ -34,7 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured: 6.3 TB/s read stream, 4.7-5.2 TB/s copy (tools/micro/hbm_stream.hip)
 
 CONFIGS = {
     "c2": dict(n_inds=1000, n_gaps=60, storage="f64", chains=4, name="synthetic 1000 ind x 60 gaps, fp64, 4 chains/GPU"),

@@ -1277,7 +1277,7 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
   std::vector<int64_t> acc((size_t)n, 0), prop((size_t)n, 0);
   for (int64_t k = 0; k < n_iter; ++k) {
     // ---- NUTS: all chains advance one leapfrog per launch until every tree has stopped ----
-    for (auto& a : s->ch) a.nuts.begin();
+    for (auto& a : s->ch) a.begin();
     for (;;) {
       int m = 0;
       for (int j = 0; j < n; ++j) {

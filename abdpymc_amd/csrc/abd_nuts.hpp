@@ -18,7 +18,7 @@
 // Step size: dual averaging (Hoffman & Gelman 2014, eq. 6; PyMC's constants gamma 0.05, t0 10, kappa 0.75,
 // initial step 0.25 / d^(1/4), mu = log(10 * initial)).  Metric: running weighted variance of the tuning
 // draws with a foreground and a background window of 101 draws (PyMC's QuadPotentialDiagAdapt; initial
-// variance 1 with weight 10).  PyMC itself is not importable offline: these constants are restated from its
+// variance 1 with weight 10).  Tree depth is capped at 8 during the first 200 tuning draws (PyMC's early_max_treedepth).  PyMC itself is not importable offline: these constants are restated from its
 // documentation and the tests check the sampler on closed-form targets, not against PyMC draws.
 //
 // Optional dense metric (PyMC: init="adapt_full"): M^-1 = regularised covariance of the tuning draws, refreshed at
@@ -445,10 +445,12 @@ struct AdaptiveNuts {
   int64_t slow_begin = 0, slow_end = 0, win_end = 0, win_len = 0;
   double target = 0.8;
   int64_t tune = 0, it = 0;
+  int max_depth_full = 10, early_max_depth = 8;  // PyMC: early_max_treedepth = 8 during the first 200 tuning draws
   void init(const double* q0, double lp0, const double* g0, uint64_t seed, uint64_t stream, int64_t n_tune,
             int max_depth, double target_accept, bool dense = false) {
     nuts.init(q0, lp0, g0, seed, stream);
     nuts.max_depth = max_depth;
+    max_depth_full = max_depth;
     nuts.eps = 0.25 / std::pow((double)D, 0.25);
     target = target_accept;
     da.init(nuts.eps, target_accept);
@@ -467,6 +469,11 @@ struct AdaptiveNuts {
     it = 0;
   }
   bool tuning() const { return it < tune; }
+  // start the transition of iteration `it`
+  void begin() {
+    nuts.max_depth = (it < tune && it < 200 && early_max_depth < max_depth_full) ? early_max_depth : max_depth_full;
+    nuts.begin();
+  }
   // call when the transition of iteration `it` has finished
   void end_transition() {
     if (it < tune) {

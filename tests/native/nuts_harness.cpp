@@ -33,7 +33,7 @@ extern "C" int nuts_harness_run(const double* mean, const double* sd, const doub
     ch[c].init(q0, lp0, g0, seed, (unsigned long long)c, tune, 10, 0.8, dense != 0);
   }
   for (long long it = 0; it < tune + draws; ++it) {
-    for (int c = 0; c < n_chains; ++c) ch[c].nuts.begin();
+    for (int c = 0; c < n_chains; ++c) ch[c].begin();
     bool any = true;
     while (any) {
       any = false;

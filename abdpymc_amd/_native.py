@@ -66,6 +66,18 @@ class _SamplerOpts(C.Structure):
     ]
 
 
+class _Record(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64),
+        ("first", C.c_int64),
+        ("i_raw", C.POINTER(C.c_int8)),
+        ("ab_s_waner", C.POINTER(C.c_int8)),
+        ("i", C.POINTER(C.c_int8)),
+        ("ab_n_mu", C.POINTER(C.c_double)),
+        ("ab_s_mu", C.POINTER(C.c_double)),
+    ]
+
+
 N_STATS = 10
 STAT_NAMES = ("lp", "tree_depth", "n_steps", "mean_tree_accept", "step_size", "diverging", "energy", "max_energy_error",
               "gibbs_accepted", "gibbs_proposed")
@@ -100,6 +112,7 @@ SYMBOLS = {
     "abd_sampler_create": (C.c_int, [_P, C.c_int32, _I32, _D, C.POINTER(_SamplerOpts), C.POINTER(_P)]),
     "abd_sampler_destroy": (None, [_P]),
     "abd_sampler_run": (C.c_int, [_P, C.c_int64, _D, _D]),
+    "abd_sampler_run_record": (C.c_int, [_P, C.c_int64, _D, _D, C.POINTER(_Record)]),
     "abd_sampler_means": (C.c_int, [_P, C.c_int32, _D, _D, _D, C.POINTER(C.c_int64)]),
     "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
@@ -417,6 +430,33 @@ class NativeSampler:
         theta = np.empty((self.n, n_iter, N_THETA))
         stats = np.empty((self.n, n_iter, N_STATS))
         _check(self._lib, self._lib.abd_sampler_run(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double)))
+        return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}
+
+    def run_record(self, n_iter: int, first: int, i_raw=None, ab_s_waner=None, i=None, ab_n_mu=None, ab_s_mu=None):
+        """
+        run() that also writes every iteration's discrete state / Deterministics of every chain into the given
+        C-contiguous arrays of shape (n, capacity, G, N) (int8 for i_raw and i, float64 for the two mu) and
+        (n, capacity, N) int8 for ab_s_waner, at draws first .. first + n_iter - 1.
+        """
+        G, N = self._ctx.n_gaps, self._ctx.n_inds
+        rec = _Record()
+        cap = None
+        for name, arr, dt, tail in (("i_raw", i_raw, np.int8, (G, N)), ("ab_s_waner", ab_s_waner, np.int8, (N,)),
+                                    ("i", i, np.int8, (G, N)), ("ab_n_mu", ab_n_mu, np.float64, (G, N)),
+                                    ("ab_s_mu", ab_s_mu, np.float64, (G, N))):
+            if arr is None:
+                continue
+            if arr.dtype != dt or not arr.flags.c_contiguous or arr.shape[0] != self.n or arr.shape[2:] != tail:
+                raise ValueError(f"{name}: need a C-contiguous {np.dtype(dt).name} array of shape (n, capacity) + {tail}")
+            if cap is not None and arr.shape[1] != cap:
+                raise ValueError("record arrays differ in capacity")
+            cap = arr.shape[1]
+            setattr(rec, name, _ptr(arr, C.c_int8 if dt == np.int8 else C.c_double))
+        rec.capacity, rec.first = int(cap or 0), int(first)
+        theta = np.empty((self.n, n_iter, N_THETA))
+        stats = np.empty((self.n, n_iter, N_STATS))
+        _check(self._lib, self._lib.abd_sampler_run_record(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double),
+                                                           C.byref(rec)))
         return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}
 
     def means(self, k: int):

@@ -1175,6 +1175,10 @@ struct abd_sampler {
   int64_t it = 0;
   double* d_sums = nullptr;  // [n][3][G*N]
   int64_t n_accumulated = 0;
+  // recording: device staging of up to rec_chunk draws per chain, [n][rec_chunk][...] per variable
+  int64_t rec_chunk = 0;
+  double* d_rec_mu = nullptr;   // [2][n][rec_chunk][G*N]  (ab_n_mu, ab_s_mu)
+  int8_t* d_rec_i8 = nullptr;   // [2][n][rec_chunk][G*N]  (i_raw, i) then [n][rec_chunk][N] (waner)
   // scratch of one lock-step round
   std::vector<int32_t> ids, who;
   std::vector<double> th, lp, gr;
@@ -1261,19 +1265,94 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
 
 void abd_sampler_destroy(abd_sampler* s) {
   if (!s) return;
-  if (s->d_sums) {
+  if (s->d_sums || s->d_rec_mu || s->d_rec_i8) {
     (void)hipSetDevice(s->c->device);
     (void)hipStreamSynchronize(s->c->stream);
-    (void)hipFree(s->d_sums);
+    if (s->d_sums) (void)hipFree(s->d_sums);
+    if (s->d_rec_mu) (void)hipFree(s->d_rec_mu);
+    if (s->d_rec_i8) (void)hipFree(s->d_rec_i8);
   }
   delete s;
 }
 
 int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats) {
+  return abd_sampler_run_record(s, n_iter, theta, stats, nullptr);
+}
+
+namespace {
+
+// copy staged draws [0, filled) of every chain to the caller's arrays, starting at draw `first`
+int record_flush(abd_sampler* s, const abd_record* rec, int64_t first, int64_t filled) {
+  if (filled == 0) return ABD_OK;
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
+  const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
+  for (int k = 0; k < s->n; ++k) {
+    const size_t dev = (size_t)k * s->rec_chunk, host = (size_t)k * rec->capacity + first;
+    if (rec->ab_n_mu) HIP_TRY(hipMemcpyAsync(rec->ab_n_mu + host * cells, s->d_rec_mu + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (rec->ab_s_mu) HIP_TRY(hipMemcpyAsync(rec->ab_s_mu + host * cells, s->d_rec_mu + per_var + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (rec->i_raw) HIP_TRY(hipMemcpyAsync(rec->i_raw + host * cells, s->d_rec_i8 + dev * cells, filled * cells, hipMemcpyDeviceToHost, c->stream));
+    if (rec->i) HIP_TRY(hipMemcpyAsync(rec->i + host * cells, s->d_rec_i8 + per_var + dev * cells, filled * cells, hipMemcpyDeviceToHost, c->stream));
+    if (rec->ab_s_waner) HIP_TRY(hipMemcpyAsync(rec->ab_s_waner + host * N, s->d_rec_i8 + 2 * per_var + dev * N, filled * N, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ABD_OK;
+}
+
+// stage the current draw of every chain at position `pos` of the chunk (all asynchronous on the stream)
+int record_stage(abd_sampler* s, const abd_record* rec, int64_t pos) {
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
+  const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
+  const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
+  const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+  for (int k = 0; k < s->n; ++k) {
+    const size_t at = ((size_t)k * s->rec_chunk + pos);
+    const ChainSlot& slot = c->slots[(size_t)s->chains[(size_t)k]];
+    if (rec->i || rec->ab_n_mu || rec->ab_s_mu) {
+      EvalArgs a;
+      base_args(c, a);
+      a.n_chains = 1;
+      a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
+      hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a,
+                         rec->i ? s->d_rec_i8 + per_var + at * cells : (int8_t*)nullptr,
+                         rec->ab_n_mu ? s->d_rec_mu + at * cells : (double*)nullptr,
+                         rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, (double*)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+    if (rec->i_raw) {
+      dim3 grid((c->N + 255) / 256, c->G);
+      hipLaunchKernelGGL(abd_unpack_bits_kernel, grid, dim3(256), 0, c->stream, slot.rw, s->d_rec_i8 + at * cells, c->G, c->N);
+      HIP_TRY(hipGetLastError());
+    }
+    if (rec->ab_s_waner)
+      HIP_TRY(hipMemcpyAsync(s->d_rec_i8 + 2 * per_var + at * N, slot.waner, N, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return ABD_OK;
+}
+
+}  // namespace
+
+int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec) {
   if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
   if (n_iter < 0) return fail(ABD_ERR_ARG, "n_iter=%lld is negative", (long long)n_iter);
   abd_ctx* c = s->c;
   const int n = s->n;
+  const bool recording = rec && (rec->i_raw || rec->ab_s_waner || rec->i || rec->ab_n_mu || rec->ab_s_mu);
+  if (recording) {
+    if (rec->first < 0 || rec->first + n_iter > rec->capacity)
+      return fail(ABD_ERR_ARG, "record: draws [%lld, %lld) do not fit capacity %lld", (long long)rec->first,
+                  (long long)(rec->first + n_iter), (long long)rec->capacity);
+    if (!s->d_rec_mu) {
+      HIP_TRY(hipSetDevice(c->device));
+      const size_t cells = (size_t)c->G * c->N;
+      const size_t per_draw = (size_t)n * (cells * 18 + c->N);  // bytes staged per draw, all chains
+      s->rec_chunk = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)(((size_t)256 << 20) / per_draw)));
+      HIP_TRY(hipMalloc(&s->d_rec_mu, (size_t)2 * n * s->rec_chunk * cells * sizeof(double)));
+      HIP_TRY(hipMalloc(&s->d_rec_i8, (size_t)2 * n * s->rec_chunk * cells + (size_t)n * s->rec_chunk * c->N));
+    }
+  }
+  int64_t staged = 0, flushed_to = recording ? rec->first : 0;
   std::vector<int64_t> acc((size_t)n, 0), prop((size_t)n, 0);
   for (int64_t k = 0; k < n_iter; ++k) {
     // ---- NUTS: all chains advance one leapfrog per launch until every tree has stopped ----
@@ -1328,8 +1407,19 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
       int rc = sampler_accumulate(s);
       if (rc) return rc;
     }
+    if (recording) {
+      int rc = record_stage(s, rec, staged);
+      if (rc) return rc;
+      if (++staged == s->rec_chunk) {
+        rc = record_flush(s, rec, flushed_to, staged);
+        if (rc) return rc;
+        flushed_to += staged;
+        staged = 0;
+      }
+    }
     s->it += 1;
   }
+  if (recording) return record_flush(s, rec, flushed_to, staged);
   return ABD_OK;
 }
 

@@ -318,7 +318,6 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
     while left > 0:
         advance(min(chunk, left))
         left -= min(chunk, left)
-    per_draw = record_deterministics or record_discrete
     thetas, stats = [], []
     out_i_raw = np.empty((chains, draws, G, N), dtype=np.int8) if record_discrete else None
     out_w = np.empty((chains, draws, N), dtype=np.int8) if record_discrete else None
@@ -328,16 +327,19 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
                    ab_s_mu=np.empty((chains, draws, G, N)))
     k = 0
     while k < draws:
-        n = 1 if per_draw else min(chunk, draws - k)
-        th, st = advance(n)
+        n = min(chunk, draws - k)
+        if record_deterministics or record_discrete:
+            # staged on the device, copied out in large blocks straight into the arrays above
+            th, st = smp.run_record(n, k, i_raw=out_i_raw, ab_s_waner=out_w, **(det or {}))
+            n_grad += int(st["n_steps"].sum()) + n * chains
+            done += n
+            if progress is not None:
+                for c in range(chains):
+                    progress(c, done, tune + draws)
+        else:
+            th, st = advance(n)
         thetas.append(th)
         stats.append(st)
-        if per_draw:
-            for c in range(chains):
-                if record_discrete:
-                    out_i_raw[c, k], out_w[c, k] = ctx.get_discrete(c)
-                if det is not None:
-                    det["i"][c, k], det["ab_n_mu"][c, k], det["ab_s_mu"][c, k] = ctx.deterministics(c, th[c, 0])
         k += n
     out_q = np.concatenate(thetas, axis=1) if thetas else np.empty((chains, 0, len(THETA_NAMES)))
     res = {name: out_q[:, :, j].copy() for j, name in enumerate(THETA_NAMES)}

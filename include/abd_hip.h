@@ -191,6 +191,22 @@ void abd_sampler_destroy(abd_sampler* s);
 /* Advance every chain by n_iter iterations.  theta: n x n_iter x 17, stats: n x n_iter x ABD_N_STATS
  * (either may be NULL).  The discrete state after the call is read with abd_get_discrete. */
 int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats);
+
+/* abd_sampler_run that also records, for every iteration of the call, the discrete state and the three
+ * Deterministics of every chain -- what the reference keeps per draw in its InferenceData (abd.py:427, 373,
+ * 649/667, 341, 389-391).  Each array is [n][capacity][...] (chain-major; (G, N) or (N,) per draw, as PyMC stores
+ * them) and this call fills draws first .. first + n_iter - 1 of every chain; NULL arrays are skipped.  The
+ * draws are staged on the device and copied out in large blocks (at config 3 a draw is 36 MB per chain). */
+typedef struct abd_record {
+  int64_t capacity;
+  int64_t first;
+  int8_t* i_raw;
+  int8_t* ab_s_waner;
+  int8_t* i;
+  double* ab_n_mu;
+  double* ab_s_mu;
+} abd_record;
+int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec);
 /* Posterior means of the Deterministics of chain k (0 <= k < n) over the draws accumulated so far, each
  * (G, N); any pointer may be NULL.  *n_draws receives the number of accumulated draws. */
 int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu_mean, double* ab_s_mu_mean,

@@ -337,3 +337,48 @@ def test_back_to_back_synchronous_calls_are_deterministic(test_td):
         else:
             assert np.array_equal(th, ref), r
     m.close()
+
+
+def test_run_record_equals_draw_by_draw_readback(test_td):
+    """The batched recorder (device staging, block copies) against reading every draw back one at a time."""
+    from abdpymc_amd.model import model
+
+    m = model(test_td, splits=(14, 20), n_chains=2)
+    ctx = m.ctx
+    G, N = test_td.n_gaps, test_td.n_inds
+    q0 = _start(m, 2)
+    a = ctx.sampler([0, 1], q0, tune=10, seed=4)
+    a.run(10)
+    rec = dict(i_raw=np.full((2, 12, G, N), -1, np.int8), ab_s_waner=np.full((2, 12, N), -1, np.int8),
+               i=np.full((2, 12, G, N), -1, np.int8), ab_n_mu=np.full((2, 12, G, N), np.nan), ab_s_mu=np.full((2, 12, G, N), np.nan))
+    th1, _ = a.run_record(5, 0, **rec)
+    assert np.all(rec["i_raw"][:, 5:] == -1) and np.all(np.isnan(rec["ab_n_mu"][:, 5:]))  # later draws untouched
+    th2, _ = a.run_record(7, 5, **rec)
+    a.close()
+    th = np.concatenate([th1, th2], axis=1)
+    # twin run, one iteration at a time
+    q0 = _start(m, 2)
+    b = ctx.sampler([0, 1], q0, tune=10, seed=4)
+    b.run(10)
+    for k in range(12):
+        t, _ = b.run(1)
+        np.testing.assert_array_equal(t[:, 0], th[:, k])
+        for c in range(2):
+            i_raw, w = ctx.get_discrete(c)
+            d_i, d_n, d_s = ctx.deterministics(c, t[c, 0])
+            np.testing.assert_array_equal(rec["i_raw"][c, k], i_raw)
+            np.testing.assert_array_equal(rec["ab_s_waner"][c, k], w)
+            np.testing.assert_array_equal(rec["i"][c, k], d_i)
+            np.testing.assert_array_equal(rec["ab_n_mu"][c, k], d_n)
+            np.testing.assert_array_equal(rec["ab_s_mu"][c, k], d_s)
+    b.close()
+    # only some variables; capacity checks
+    c2 = ctx.sampler([0, 1], _start(m, 2), tune=0, seed=4)
+    only = np.full((2, 3, G, N), np.nan)
+    c2.run_record(3, 0, ab_s_mu=only)
+    assert np.all(np.isfinite(only))
+    with pytest.raises(ValueError):
+        c2.run_record(3, 1, ab_s_mu=only)  # draws 1..3 do not fit capacity 3
+    with pytest.raises(ValueError):
+        c2.run_record(1, 0, i=np.zeros((2, 3, G, N)))  # wrong dtype
+    m.close()

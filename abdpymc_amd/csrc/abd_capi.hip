@@ -1348,8 +1348,16 @@ int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double
       const size_t cells = (size_t)c->G * c->N;
       const size_t per_draw = (size_t)n * (cells * 18 + c->N);  // bytes staged per draw, all chains
       s->rec_chunk = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)(((size_t)256 << 20) / per_draw)));
-      HIP_TRY(hipMalloc(&s->d_rec_mu, (size_t)2 * n * s->rec_chunk * cells * sizeof(double)));
-      HIP_TRY(hipMalloc(&s->d_rec_i8, (size_t)2 * n * s->rec_chunk * cells + (size_t)n * s->rec_chunk * c->N));
+      double* mu = nullptr;
+      int8_t* i8 = nullptr;
+      hipError_t e = hipMalloc(&mu, (size_t)2 * n * s->rec_chunk * cells * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&i8, (size_t)2 * n * s->rec_chunk * cells + (size_t)n * s->rec_chunk * c->N);
+      if (e != hipSuccess) {
+        if (mu) (void)hipFree(mu);
+        return fail(ABD_ERR_HIP, "record staging: %s", hipGetErrorString(e));
+      }
+      s->d_rec_mu = mu;
+      s->d_rec_i8 = i8;
     }
   }
   int64_t staged = 0, flushed_to = recording ? rec->first : 0;

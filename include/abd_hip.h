@@ -184,7 +184,8 @@ typedef struct abd_sampler_opts {
 #define ABD_STAT_GIBBS_ACCEPTED 8
 #define ABD_STAT_GIBBS_PROPOSED 9
 
-/* chains[k] must hold a discrete state (abd_set_discrete); theta0 is n x 17, the starting points. */
+/* chains[k] must hold a discrete state (abd_set_discrete); theta0 is n x 17, the starting points.
+ * A sampler points into its context: destroy it before abd_destroy(ctx). */
 int abd_sampler_create(abd_ctx* ctx, int32_t n, const int32_t* chains, const double* theta0,
                        const abd_sampler_opts* opts, abd_sampler** out);
 void abd_sampler_destroy(abd_sampler* s);

@@ -55,3 +55,28 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "libabd_oracle" not in txt, f
+
+
+def _build_c_example(out):
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "abi_example.c"), "-L", os.path.join(ROOT, "abdpymc_amd"), "-labd_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "abdpymc_amd"), "-lm", "-o", str(out)]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+def test_header_is_plain_c_and_the_example_links(tmp_path):
+    """include/abd_hip.h compiles as C99 (-pedantic -Werror) and examples/abi_example.c links against the library."""
+    from abdpymc_amd import _native
+
+    _native.load()  # built
+    r = _build_c_example(tmp_path / "abi_example")
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    r = _build_c_example(tmp_path / "abi_example")
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(tmp_path / "abi_example")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "infection found" in run.stdout

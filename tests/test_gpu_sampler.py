@@ -223,11 +223,16 @@ def test_cli_sharded_over_two_processes(tmp_path, golden_dir):
     from abdpymc_amd.model import model
     from abdpymc_amd.sampler import sample
 
+    import socket
+
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = tmp_path / "sharded"
     env = dict(os.environ, ABD_DIST_BACKEND="gloo", PYTHONPATH=root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", "-m", "abdpymc_amd.cli", "--tune", "12", "--draws", "6", "--chains", "2", "--seed", "5",
+           "--master-port", str(port), "-m", "abdpymc_amd.cli", "--tune", "12", "--draws", "6", "--chains", "2", "--seed", "5",
            "--ititers_data", os.path.join(golden_dir, "test_cohort"), "--split_delta", "--device", "0", "--netcdf", str(out)]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

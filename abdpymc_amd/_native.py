@@ -115,6 +115,8 @@ SYMBOLS = {
     "abd_sampler_run_record": (C.c_int, [_P, C.c_int64, _D, _D, C.POINTER(_Record)]),
     "abd_sampler_means": (C.c_int, [_P, C.c_int32, _D, _D, _D, C.POINTER(C.c_int64)]),
     "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
+    "abd_theta_prior": (C.c_int, [_P, _D, _D, _D]),
+    "abd_set_individual_offset": (C.c_int, [_P, C.c_int64]),
     "abd_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
@@ -380,6 +382,19 @@ class Context:
             ),
         )
         return i, mun, mus
+
+    def theta_prior(self, theta):
+        """The theta-only part of the joint logp (continuous priors + Jacobians) and its gradient."""
+        t = _as(theta, np.float64)
+        if t.shape != (N_THETA,):
+            raise ValueError(f"theta must have shape ({N_THETA},)")
+        out = C.c_double()
+        g = np.empty(N_THETA)
+        _check(self._lib, self._lib.abd_theta_prior(self._h, _ptr(t, C.c_double), C.byref(out), _ptr(g, C.c_double)))
+        return out.value, g
+
+    def set_individual_offset(self, first_individual: int):
+        _check(self._lib, self._lib.abd_set_individual_offset(self._h, int(first_individual)))
 
     def sampler(self, chains, theta0, tune: int, seed: int = 0, target_accept: float = 0.8, max_treedepth: int = 10,
                 gibbs: bool = True, accumulate: bool = False, chain_offset: int = 0,

@@ -113,6 +113,7 @@ struct abd_ctx {
   hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
+  uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;
   double prior_const = 0.0;
@@ -1043,7 +1044,7 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
     ga.seed_lo = (uint32_t)seed;
     ga.seed_hi = (uint32_t)(seed >> 32);
     ga.sweep = sweep;
-    ga.pad_ = 0;
+    ga.ind_offset = c->ind_offset;
     ga.counts = c->d_counts;
     for (int k = 0; k < m; ++k) {
       const double* t = theta + (size_t)(k0 + k) * ABD_N_THETA;
@@ -1118,6 +1119,19 @@ int abd_set_launch_config(abd_ctx* c, int32_t blocks, int32_t chains_per_wave) {
     else
       c->blocks_x = std::max(1, std::min(blocks, c->blocks_max));
   }
+  return ABD_OK;
+}
+
+int abd_theta_prior(abd_ctx* c, const double* theta, double* logp, double* grad) {
+  if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  *logp = priors(theta, c->G, 0.0, 0.0, 0.0, 0.0, grad, c->prior_const);
+  return ABD_OK;
+}
+
+int abd_set_individual_offset(abd_ctx* c, int64_t first_individual) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (first_individual < 0 || first_individual > 0xFFFFFFFFll) return fail(ABD_ERR_ARG, "first_individual=%lld out of range", (long long)first_individual);
+  c->ind_offset = (uint32_t)first_individual;
   return ABD_OK;
 }
 

@@ -54,7 +54,8 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 
 struct GibbsArgs {
   EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)
-  uint32_t seed_lo, seed_hi, sweep, pad_;
+  uint32_t seed_lo, seed_hi, sweep;
+  uint32_t ind_offset;  // added to the individual's index in the Philox counter (cohort sharded by individual)
   uint32_t stream[ABD_MAX_BATCH_K];  // third counter word of each chain: its slot id (+ the caller's offset)
   double theta0[ABD_MAX_BATCH_K];  // log p - log(1 - p)             = p_logodds__
   double theta7[ABD_MAX_BATCH_K];  // log p_waner - log(1 - p_waner) = ab_s_p_waner_logodds__
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
 
     // ---- random order and transit flags of this individual's dims ----
     for (int d = lane; d < n_dims; d += 64) {
-      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j, cs, 0u, k0, k1);
+      const Philox4 r = philox4x32_10((uint32_t)d, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
       keyv[d] = (r.w[0] & ~0x1FFu) | (uint32_t)d;
       transit[d] = r.w[1] < ABD_TRANSIT_P_U32 ? 1 : 0;
       logu[d] = log(((double)r.w[2] + 0.5) * (1.0 / 4294967296.0));  // one log per lane and dim, not one per proposal

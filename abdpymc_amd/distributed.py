@@ -94,3 +94,75 @@ def init_from_env():
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return dist, rank, world, local
+
+
+# ---------------------------------------------------------------------------------------------------
+# One chain over several GPUs: the cohort sharded by individual (second way)
+# ---------------------------------------------------------------------------------------------------
+
+
+def slice_individuals(data, j0: int, j1: int):
+    """The TiterData of individuals [j0, j1): their observations (re-indexed from 0), vaccinations and PCR+ rows."""
+    from .data import TiterData
+
+    def obs(a):
+        keep = (a.idx_ind >= j0) & (a.idx_ind < j1)
+        return a.idx_gap[keep], a.idx_ind[keep] - j0, a.log_dilution[keep], a.od[keep]
+
+    return TiterData.from_arrays(data.n_gaps, j1 - j0, obs(data.s), obs(data.n), np.asarray(data.vacs)[j0:j1],
+                                 np.asarray(data.pcrpos)[j0:j1], t0=data.t0)
+
+
+class IndividualShards:
+    """
+    This process's slice of a cohort sharded by individual over ``dist``'s ranks (one per GPU), with the joint logp
+    and its gradient put back together by ONE all-reduce of 18 doubles per evaluation:
+    ``sum over ranks of logp_r - (world - 1) * theta_prior`` (every rank's own logp carries the theta-only terms
+    once).  The Gibbs sweep touches only a rank's own individuals and needs no exchange; it draws the random
+    numbers of each individual's global index, so the sharded sweep is the unsharded one bit for bit.
+    """
+
+    def __init__(self, data, dist=None, splits=None, ignore_pcrpos=False, n_chains=1, device=-1, all_reduce_device=None):
+        from .model import AbdModel
+
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        counts = split_counts(data.n_inds, self.world)
+        self.j0 = sum(counts[: self.rank])
+        self.j1 = self.j0 + counts[self.rank]
+        if self.j1 == self.j0:
+            raise ValueError(f"{data.n_inds} individuals cannot be sharded over {self.world} processes")
+        self.model = AbdModel(slice_individuals(data, self.j0, self.j1), splits=splits, ignore_pcrpos=ignore_pcrpos,
+                              n_chains=n_chains, device=device)
+        self.model.ctx.set_individual_offset(self.j0)
+        self._device = all_reduce_device
+
+    def set_discrete(self, chain: int, i_raw, waner):
+        """i_raw (G, N) and waner (N,) of the WHOLE cohort; this rank keeps its columns."""
+        self.model.ctx.set_discrete(chain, np.asarray(i_raw)[:, self.j0:self.j1], np.asarray(waner)[self.j0:self.j1])
+
+    def get_discrete(self, chain: int):
+        """This rank's columns: i_raw (G, j1 - j0), waner (j1 - j0,)."""
+        return self.model.ctx.get_discrete(chain)
+
+    def logp_dlogp(self, chain: int, theta):
+        lp, g = self.model.ctx.logp_dlogp(chain, theta)
+        if self.dist is None:
+            return lp, g
+        import torch
+
+        buf = torch.from_numpy(np.concatenate([[lp], g]))
+        if self._device is not None:
+            buf = buf.to(self._device)
+        self.dist.all_reduce(buf)  # sum: RCCL over xGMI with backend "nccl"
+        tot = buf.cpu().numpy()
+        plp, pg = self.model.ctx.theta_prior(theta)
+        return float(tot[0] - (self.world - 1) * plp), tot[1:] - (self.world - 1) * pg
+
+    def gibbs_sweep(self, chains, theta, seed: int, sweep: int):
+        """Local sweep of this rank's individuals -> (accepted, proposed) of this rank."""
+        return self.model.ctx.gibbs_sweep(chains, theta, seed=seed, sweep=sweep)
+
+    def close(self):
+        self.model.close()

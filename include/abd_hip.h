@@ -216,6 +216,18 @@ int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu
  * M^-1 (the diagonal matrix when the metric is diagonal). */
 int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric);
 
+/* ---------------------------------------------------------------------------------------------------
+ * One chain over several GPUs (cohorts too large or too slow for one): the joint logp is a sum over
+ * individuals plus terms of theta alone, so each process holds a context over ITS slice of the individuals and
+ *   logp(theta) = sum over processes of abd_logp_dlogp(...)  -  (processes - 1) x abd_theta_prior(theta)
+ * (likewise the gradient): one all-reduce of 18 doubles per evaluation.  The Gibbs sweep needs no exchange at all;
+ * abd_set_individual_offset makes it draw the random numbers of the individual's GLOBAL index, so the sharded
+ * sweep is bit-identical to the unsharded one.  Python: abdpymc_amd.distributed.IndividualShards. */
+/* The part of the joint logp that depends on theta only (continuous priors + log-Jacobians; no Bernoulli
+ * term, no data term) and its gradient (may be NULL). */
+int abd_theta_prior(abd_ctx* ctx, const double* theta, double* logp, double* grad);
+int abd_set_individual_offset(abd_ctx* ctx, int64_t first_individual);
+
 /* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
  * events on the stream it is launched on, and stream-ordered launches all go to ONE stream (normally they
  * alternate between two, so that the head of a launch overlaps the tail of the previous one: a launch's

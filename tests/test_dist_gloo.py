@@ -67,3 +67,19 @@ def test_sharding_helpers():
         chain_ids_for_rank(2, 2, 1)
     b = np.arange(6.0).reshape(2, 3)
     np.testing.assert_array_equal(gather_samples(b), b[None])
+
+
+def test_slice_individuals():
+    from abdpymc_amd import synthetic
+    from abdpymc_amd.data import TiterData
+    from abdpymc_amd.distributed import slice_individuals
+
+    sc = synthetic.make_cohort(11, 6, seed=2)
+    td = TiterData.from_arrays(6, 11, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos)
+    part = slice_individuals(td, 4, 9)
+    assert part.n_inds == 5 and part.n_gaps == 6 and len(part.s) == 5 * 6 and len(part.n) == 5 * 6
+    assert part.s.idx_ind.min() == 0 and part.s.idx_ind.max() == 4
+    np.testing.assert_array_equal(part.vacs, np.asarray(td.vacs)[4:9])
+    keep = (td.n.idx_ind >= 4) & (td.n.idx_ind < 9)
+    np.testing.assert_array_equal(part.n.od, td.n.od[keep])
+    np.testing.assert_array_equal(part.n.idx_gap, td.n.idx_gap[keep])

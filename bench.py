@@ -139,7 +139,10 @@ def main():
     t_warm = time.perf_counter()
     while time.perf_counter() - t_warm < 0.015:
         run_steps(0, max(W, 8) if W + K >= 8 else W + K)
+    t_b = time.perf_counter()
     barrier()
+    if os.environ.get("ABD_BENCH_DEBUG"):
+        print(f"[bench debug] opening barrier {(time.perf_counter() - t_b) * 1e3:.3f} ms", file=sys.stderr)
     t0 = time.perf_counter()
     run_steps(W, W + K, lp_all, g_all)
     if dist is not None:

@@ -197,7 +197,9 @@ def main():
         traffic=traffic, kernel="abd_dense_kernel", kernel_us=round(k_avg_s * 1e6, 3), launches=int(k_n),
         algorithmic_bytes_per_launch=int(alg_bytes), survey_bytes_per_launch=int(survey_bytes), evals_per_launch=C,
         overlapped_us_per_launch=round(elapsed / K * 1e6, 3),
-        note="achieved uses the smaller, bit-packed byte count; the kernel is fp64-VALU bound (see DESIGN.md)",
+        note="achieved uses the smaller, bit-packed byte count; the kernel is fp64-VALU bound (see DESIGN.md). kernel_us is "
+             "ONE launch alone on the chip (instrumented pass, one stream, full grid); in the timed region three launches "
+             "share the chip (3 streams x 1 workgroup per CU) and one completes every overlapped_us_per_launch",
     )
 
     # ---- CPU baseline: plain-C OpenMP restatement on the host cores (rank 0, N=1 only) ----

@@ -376,11 +376,13 @@ int pick_cpw(const abd_ctx* c, int n) {
 
 // grid of the dense kernel: an exact multiple of the CU count (every wave slot gets the same number of
 // gap rows), capped so a slot has at least kMinRows rows
-int dense_blocks(const abd_ctx* c, int cpw, bool shared = false) {
+int dense_blocks(const abd_ctx* c, int cpw, bool shared = false, int grid_rows = 1) {
   const int nsub = ABD_WAVES_PER_BLOCK / cpw;
   const int64_t rows = (int64_t)c->n_lg * c->G;
   const int64_t cap = std::max<int64_t>(1, rows / ((int64_t)kMinRows * nsub));
-  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(shared ? c->pipe_blocks : c->dense_blocks), cap, (int64_t)c->blocks_max}));
+  // a launch with several grid rows (more than 4 chains) fills the chip with fewer, longer ranges per row
+  const int64_t alone = std::max<int64_t>(c->n_cu, c->dense_blocks / std::max(1, grid_rows));
+  return (int)std::max<int64_t>(1, std::min<int64_t>({shared ? (int64_t)c->pipe_blocks : alone, cap, (int64_t)c->blocks_max}));
 }
 
 // queue the standalone fixed-order sum of a launch whose partials are still pending
@@ -432,7 +434,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     blocks = c->ob_n + c->ob_s + c->ob_c;
     lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
   } else if (c->dense) {
-    blocks = dense_blocks(c, cpw, rotate);
+    blocks = dense_blocks(c, cpw, rotate, n / cpw);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
   } else {
     blocks = c->blocks_x;

@@ -404,8 +404,10 @@ class Context:
                              dense_metric)
 
     # -- measurement --------------------------------------------------------------------------
-    def kernel_timing(self, enable: bool):
-        _check(self._lib, self._lib.abd_kernel_timing(self._h, int(enable)))
+    def kernel_timing(self, mode):
+        """0/False off; 1/True HIP events per launch, launches serialised (isolated kernel); 2 per window of
+        stream-ordered launches in their real launch shape."""
+        _check(self._lib, self._lib.abd_kernel_timing(self._h, int(mode)))
 
     def set_launch_config(self, blocks: int = 0, chains_per_wave: int = 0):
         _check(self._lib, self._lib.abd_set_launch_config(self._h, int(blocks), int(chains_per_wave)))

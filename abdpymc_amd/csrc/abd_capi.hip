@@ -125,8 +125,12 @@ struct abd_ctx {
   int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
   std::vector<ResultSlot> results;
   hipStream_t stream = nullptr;
-  // timing
-  bool timing = false;
+  // timing: 1 = HIP events around every evaluation-kernel launch, launches serialised on one stream with the full
+  // grid (the isolated kernel); 2 = HIP events around every WINDOW of stream-ordered launches (first launch after an
+  // abd_wait .. all pipes joined at the next abd_wait): the launch shape a stream-ordered caller really runs
+  int timing = 0;
+  bool win_open = false;
+  int64_t win_launches = 0;  // launches inside the windows collected so far
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double ev_total_ms = 0.0;
@@ -427,7 +431,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   const bool lanes = !c->dense && c->obs_lanes;
   const int cpw = lanes ? 1 : pick_cpw(c, n);
   // stream-ordered dense launches rotate over the pipes; everything else runs on pipe 0 after a join
-  const bool rotate = deferred && c->n_pipes > 1 && c->dense && c->fuse_finalize && !c->timing;  // timing: one launch at a time
+  const bool rotate = deferred && c->n_pipes > 1 && c->dense && c->fuse_finalize && c->timing != 1;  // timing 1: one launch at a time
   int blocks;
   size_t lds;
   if (lanes) {
@@ -469,7 +473,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     if (frc) return frc;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->timing) {
+  if (c->timing == 1 || (c->timing == 2 && deferred && !c->win_open)) {
     if (c->ev_used == c->ev_pool.size()) {
       hipEvent_t a0, a1;
       HIP_TRY(hipEventCreate(&a0));
@@ -478,9 +482,13 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     }
     e0 = c->ev_pool[c->ev_used].first;
     e1 = c->ev_pool[c->ev_used].second;
-    c->ev_used++;
+    if (c->timing == 1) c->ev_used++;
+    // window mode: every pipe is idle here (the previous abd_wait joined and synchronised them), so the stream of
+    // the window's first launch carries its start; the end is recorded by flush_ring once all pipes have joined
     HIP_TRY(hipEventRecord(e0, pp.st));
+    if (c->timing == 2) c->win_open = true;
   }
+  if (c->timing == 2 && deferred) c->win_launches++;
   hipError_t le;
   if (lanes)
     le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, pp.st, a)
@@ -491,7 +499,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   else
     le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, pp.st, a)
                                      : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);
-  if (c->timing) HIP_TRY(hipEventRecord(e1, pp.st));
+  if (c->timing == 1) HIP_TRY(hipEventRecord(e1, pp.st));
   HIP_TRY(le);
   pp.on = true;
   pp.buf = buf;
@@ -506,6 +514,11 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
 
 int flush_ring(abd_ctx* c) {
   if (int prc = flush_pending(c)) return prc;
+  if (c->win_open) {  // timing 2: the window closes once every pipe's last launch and sum have joined the context's stream
+    HIP_TRY(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
+    c->ev_used++;
+    c->win_open = false;
+  }
   if (c->ring_lo < c->ring_hi) {
     const size_t row = (size_t)c->n_slots * ABD_NOUT;
     const int64_t count = (int64_t)(c->ring_hi - c->ring_lo) * row;
@@ -1137,22 +1150,32 @@ int abd_set_individual_offset(abd_ctx* c, int64_t first_individual) {
   return ABD_OK;
 }
 
-int abd_kernel_timing(abd_ctx* c, int32_t enable) {
+int abd_kernel_timing(abd_ctx* c, int32_t mode) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
-  c->timing = enable != 0;
+  if (mode < 0 || mode > 2) return fail(ABD_ERR_ARG, "timing mode %d outside {0, 1, 2}", mode);
+  if (mode != c->timing) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (int frc = flush_ring(c)) return frc;  // closes an open window, joins the pipes
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->timing = mode;
   return ABD_OK;
 }
 
 int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t reset) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  if (int jrc = join_pipes(c)) return jrc;
+  if (int frc = flush_ring(c)) return frc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (size_t k = 0; k < c->ev_used; ++k) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
     c->ev_total_ms += ms;
-    c->ev_count++;
+    if (c->timing != 2) c->ev_count++;
+  }
+  if (c->timing == 2) {
+    c->ev_count += c->win_launches;
+    c->win_launches = 0;
   }
   c->ev_used = 0;
   if (total_ms) *total_ms = c->ev_total_ms;

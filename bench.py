@@ -6,26 +6,35 @@ Metric (BASELINE.json): "logp+grad evals/sec, 10k-ind x 200-gap cohort".  Worklo
 config 3: synthetic 10 000 individuals x 200 gaps, fp64, 4 chains on one GPU.  One *step* = one batched
 logp+dlogp call for the rank's 4 chains at 4 fresh thetas (= 4 evaluations; the shared OD panels are
 read once per launch).  For N>1 GPUs every rank holds its own 4 chains (config 4 at N=8: 32 chains,
-weak scaling, no data-path collective) and the (steps x chains x 18) sample block is gathered over RCCL
-once at the end of the timed region.
+weak scaling, no data-path collective); the (steps x chains x 18) sample block is gathered over RCCL
+once after the timed region and timed on its own (`gather_ms`).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
+(`python -m torch.distributed.run ...`, before this process has touched the GPU) and passes rank 0's line on.
 
 Timed region: K steps enqueued stream-ordered (the library rotates them over three HIP streams so that
-launches share the chip instead of draining it one after the other), one wait, results fetched (host-side prior terms included),
-bracketed by barrier + device sync.  Inputs are resident in HBM before it starts.  Warm-up: W untimed steps
-as asked, repeated until at least 60 ms have passed -- after an idle period the part needs ~3 ms of load to
-reach its sustained state, which 20 steps (0.6 ms) do not cover.
+launches share the chip instead of draining it one after the other), one wait, results fetched (host-side
+prior terms included), opened by barrier + device sync, closed by a device sync; MAX over ranks.  Inputs
+are resident in HBM before it starts.  The K-step region is repeated R times (until >= 0.25 s of timed work,
+R <= 400): `value` and `ms_per_step` are the MEDIAN region, `region_ms` holds min / median / max.  Warm-up:
+W untimed steps as asked, repeated until at least 60 ms have passed -- after an idle period the part needs
+~3 ms of load to reach its sustained state, which 20 steps (0.5 ms) do not cover.
 
-Also reported in the same JSON line:
-  roofline     algorithmic bytes per launch / mean kernel time against 8 TB/s HBM.  The kernel time is taken with
-               HIP events on the launch stream in an instrumented second pass over the same steps, in which
-               launches are serialised on ONE stream (a launch's own duration means nothing while another
-               one is in flight); `overlapped_us_per_launch` is the timed region's wall time per launch
-  cpu_baseline the plain-C OpenMP restatement (oracle/abd_oracle.c) on the host cores, bounded sample
-  sync_evals_per_s   rate seen by a caller that waits for every step (a sequential NUTS leapfrog chain)
+Also in the same JSON line:
+  roofline     the TIMED launch shape: device time per launch from HIP events around every window of K
+               stream-ordered launches (first launch .. all streams joined; abd_kernel_timing mode 2), against
+               8 TB/s HBM with the algorithmic bytes of one launch.  `roofline.isolated` is ONE launch alone on
+               the chip (one stream, full grid; mode 1), `roofline.valu` the roof that actually binds: vector
+               instructions per launch (rocprofv3 PMC, profiles/) against the fp64 vector peak
+  cpu_baseline the plain-C OpenMP restatement (oracle/abd_oracle.c) on the host cores, its 1-thread rate, and B0,
+               the reference's own dense (G, G, N) algorithm restated in NumPy (forward only), bounded samples
+  sync_evals_per_s   rate seen by a caller that waits for every step (lock-step NUTS over the rank's chains)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,13 +43,30 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured: 6.3 TB/s read stream, 4.7-5.2 TB/s copy (tools/micro/hbm_stream.hip)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured: 6.3 TB/s read stream (tools/micro/hbm_stream.hip)
+FP64_VECTOR_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (MI355X_MICROARCH.md: half the fp32 vector rate)
 
 CONFIGS = {
     "c2": dict(n_inds=1000, n_gaps=60, storage="f64", chains=4, name="synthetic 1000 ind x 60 gaps, fp64, 4 chains/GPU"),
     "c3": dict(n_inds=10000, n_gaps=200, storage="f64", chains=4, name="synthetic 10000 ind x 200 gaps, fp64, 4 chains/GPU"),
     "c5": dict(n_inds=100000, n_gaps=200, storage="f32", chains=1, name="synthetic 100000 ind x 200 gaps, fp32 storage, 1 chain/GPU"),
 }
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_gpus):
+    """Start one rank per GPU under torch.distributed.run.  Nothing in this process has touched HIP yet."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -52,31 +78,42 @@ def main():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the config's)")
     ap.add_argument("--splits", default="", help="comma separated gap indexes, e.g. 100 or 66,133")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step region until this much timed work")
+    ap.add_argument("--max-repeats", type=int, default=400)
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
     if args.chains:
         cfg["chains"] = args.chains
     n_gpus = args.gpus
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(n_gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if n_gpus > 1 and world != n_gpus:
-        raise SystemExit(
-            f"--gpus {n_gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-            f"--nproc-per-node {n_gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {n_gpus} ..."
-        )
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: start one process per GPU (or let bench.py start them: "
+                         f"python bench.py --gpus {n_gpus})")
 
     dist = None
     torch = None
+    backend = None
+    device = local_rank
     if world > 1 or os.environ.get("ABD_BENCH_FORCE_DIST"):
-        # torch is plumbing only: rendezvous, barrier and the RCCL gather of the sample block
+        # torch is plumbing only: rendezvous, barrier and the gather of the sample block
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ABD_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; "gloo": rehearsal with ranks sharing a GPU
+        n_dev = max(1, torch.cuda.device_count())
+        device = local_rank % n_dev
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
+    comm_dev = "cuda" if backend == "nccl" else None
 
     from abdpymc_amd import synthetic
     from abdpymc_amd._native import Context
@@ -87,7 +124,7 @@ def main():
 
     sc = synthetic.make_cohort(N, G)
     ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=splits, n_chains=C,
-                  storage=cfg["storage"], device=local_rank)
+                  storage=cfg["storage"], device=device)
     chains = np.arange(C, dtype=np.int32)
     thetas = np.empty((K + W, C, 17))
     states = []
@@ -102,8 +139,19 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
         ctx.wait()
+
+    def all_max(values):
+        """element-wise MAX over ranks of a vector of per-rank times"""
+        if dist is None:
+            return np.asarray(values, dtype=np.float64)
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        if comm_dev:
+            t = t.to(comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy()
 
     def run_steps(lo, hi, out_lp=None, out_g=None):
         """enqueue steps [lo, hi) stream-ordered; fetch in windows of the result ring"""
@@ -119,97 +167,138 @@ def main():
                 out_g[s - lo:e - lo] = g
             s = e
 
+    def warm(seconds):
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < seconds:
+            run_steps(0, max(W, 8) if W + K >= 8 else W + K)
+
     # ---- warm-up: W steps, repeated until the part is at its sustained state ----
     run_steps(0, W)
-    t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.06:
-        run_steps(0, max(W, 8) if W + K >= 8 else W + K)
-    # ---- timed region: EXACTLY K steps ----
+    warm(0.06)
     lp_all = np.empty((K, C))
     g_all = np.empty((K, C, 17))
     if dist is not None:
-        # RCCL builds its communicator and buffers on first use: not part of a step
+        # the communicator and its buffers are built on first use: not part of a step
         from abdpymc_amd.distributed import gather_samples
 
-        gather_samples(np.zeros((K, C, 18)), dist, device="cuda")
-    # The first barrier absorbs the collective's start-up; the part idles meanwhile and a few ms of idling cost
-    # ~2.5 ms of ramp-up afterwards (tools/probe_idle_penalty.py), so: barrier, warm up again, then the barrier
-    # that opens the timed region (a fraction of a millisecond by now).
-    barrier()
-    t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.015:
-        run_steps(0, max(W, 8) if W + K >= 8 else W + K)
-    t_b = time.perf_counter()
-    barrier()
-    if os.environ.get("ABD_BENCH_DEBUG"):
-        print(f"[bench debug] opening barrier {(time.perf_counter() - t_b) * 1e3:.3f} ms", file=sys.stderr)
-    t0 = time.perf_counter()
-    run_steps(W, W + K, lp_all, g_all)
-    if dist is not None:
-        # the trivial RCCL gather of samples over xGMI: (world, steps, chains, 18) on every rank
-        from abdpymc_amd.distributed import gather_samples
+        gather_samples(np.zeros((K, C, 18)), dist, device=comm_dev)
 
-        gathered = gather_samples(np.concatenate([lp_all[..., None], g_all], axis=-1), dist, device="cuda")
-        assert gathered.shape == (world, K, C, 18)
-    t_steps = time.perf_counter() - t0
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("ABD_BENCH_DEBUG"):
-        print(f"[bench debug] steps+gather {t_steps * 1e3:.3f} ms, closing barrier {(elapsed - t_steps) * 1e3:.3f} ms", file=sys.stderr)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- timed: EXACTLY K steps per region, R regions ----
+    def region():
+        # barrier, W steps so the part is under load again (a barrier idles it; a few ms of idling cost ~2.5 ms of
+        # ramp-up, tools/probe_idle_penalty.py), then the barrier + sync that opens the region
+        if dist is not None:
+            barrier()
+            run_steps(0, W)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(W, W + K, lp_all, g_all)  # ends with a device sync (abd_wait) and the fetch
+        return time.perf_counter() - t0
+
+    first = float(all_max([region()])[0])
+    n_rep = int(min(args.max_repeats, max(3, np.ceil(args.min_seconds / max(first, 1e-9)))))
+    times = all_max([region() for _ in range(n_rep)])
+    elapsed = float(np.median(times))
     if not np.all(np.isfinite(lp_all)):
         raise SystemExit("non-finite logp in the timed region")
+
+    gather_ms = None
+    if dist is not None:
+        # the trivial gather of samples (RCCL over xGMI with backend nccl): (world, steps, chains, 18) on every rank
+        barrier()
+        t_g = time.perf_counter()
+        gathered = gather_samples(np.concatenate([lp_all[..., None], g_all], axis=-1), dist, device=comm_dev)
+        gather_ms = float(all_max([time.perf_counter() - t_g])[0]) * 1e3
+        assert gathered.shape == (world, K, C, 18)
 
     total_evals = K * C * world
     value = total_evals / elapsed
 
-    # ---- synchronous caller rate (each step waits for its result) ----
+    # ---- synchronous caller rate (each step waits for its result): what lock-step NUTS over these chains sees ----
     ks = min(K, 200)
-    ctx.wait()
-    t1 = time.perf_counter()
-    for k in range(W, W + ks):
-        ctx.logp_dlogp_batch(chains, thetas[k])
-    sync_rate = ks * C / (time.perf_counter() - t1)
+    sync_rates = []
+    for _ in range(3):
+        ctx.wait()
+        t1 = time.perf_counter()
+        for k in range(W, W + ks):
+            ctx.logp_dlogp_batch(chains, thetas[k])
+        sync_rates.append(ks * C / (time.perf_counter() - t1))
+    sync_rate = float(np.median(sync_rates))
 
-    # ---- kernel-only time: HIP events around every evaluation-kernel launch, same steps ----
-    ctx.kernel_timing(True)
+    # ---- device time of the timed launch shape: HIP events around every window of K stream-ordered launches ----
+    warm(0.02)
+    ctx.kernel_timing(2)
     ctx.kernel_time(reset=True)
+    for _ in range(int(min(n_rep, 40))):
+        run_steps(W, W + K)
+    w_ms, w_n = ctx.kernel_time(reset=True)
+    # ---- the isolated kernel: HIP events around every launch, one stream, full grid ----
+    ctx.kernel_timing(1)
     run_steps(W, W + K)
     k_ms, k_n = ctx.kernel_time(reset=True)
-    ctx.kernel_timing(False)
+    ctx.kernel_timing(0)
+
     alg_bytes = ctx.algorithmic_bytes(C)  # compulsory bytes of this library's layout (bit-packed indicators)
     R = 4 if cfg["storage"] == "f32" else 8
     survey_bytes = G * N * (4 * R + 2 + C) + C * N  # byte-per-cell indicator panels
+    w_avg_s = (w_ms / max(w_n, 1)) * 1e-3
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
-    achieved = alg_bytes / k_avg_s / 1e9
-    traffic = None
+    achieved = alg_bytes / w_avg_s / 1e9
+    iso_achieved = alg_bytes / k_avg_s / 1e9
+    prof = {}
     tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp):
+    if os.path.exists(tp) and not splits and C == CONFIGS[args.config]["chains"]:
         try:
-            traffic = json.load(open(tp)).get(args.config, {}).get("hbm_bytes_per_launch")
+            prof = json.load(open(tp)).get(args.config, {})
         except Exception:
-            traffic = None
+            prof = {}
+    pipe_prof = prof.get("pipe_grid", prof)
+    valu = None
+    if pipe_prof.get("valu_insts_per_launch"):
+        insts = float(pipe_prof["valu_insts_per_launch"])
+        tf = insts * 64 * 2 / w_avg_s / 1e12  # every vector instruction priced as one fp64 FMA on 64 lanes
+        valu = dict(bound="fp64-valu", insts_per_launch=int(insts), achieved_tflops_equiv=round(tf, 2), peak=FP64_VECTOR_TFLOPS,
+                    unit="TFLOP/s", frac=round(tf / FP64_VECTOR_TFLOPS, 4),
+                    insts_per_cell_chain=round(insts * 64 / (G * N * C), 2), source=pipe_prof.get("valu_source"),
+                    note="vector wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 64 lanes x 2 flop / device "
+                         "time per launch of the timed shape; 32-bit integer/select instructions issue at twice the fp64 rate, "
+                         "so 1.0 is not reachable and the lever is the instruction count")
     roofline = dict(
         bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-        traffic=traffic, kernel="abd_dense_kernel", kernel_us=round(k_avg_s * 1e6, 3), launches=int(k_n),
+        traffic=pipe_prof.get("hbm_bytes_per_launch"), kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel",
+        kernel_us=round(w_avg_s * 1e6, 3), launches=int(w_n),
+        launch_shape="stream-ordered, as timed: launches rotate over 3 HIP streams, 1 workgroup per CU each; device time "
+                     "from HIP events around each window of K launches / K",
         algorithmic_bytes_per_launch=int(alg_bytes), survey_bytes_per_launch=int(survey_bytes), evals_per_launch=C,
-        overlapped_us_per_launch=round(elapsed / K * 1e6, 3),
-        note="achieved uses the smaller, bit-packed byte count; the kernel is fp64-VALU bound (see DESIGN.md). kernel_us is "
-             "ONE launch alone on the chip (instrumented pass, one stream, full grid); in the timed region three launches "
-             "share the chip (3 streams x 1 workgroup per CU) and one completes every overlapped_us_per_launch",
+        isolated=dict(kernel_us=round(k_avg_s * 1e6, 3), achieved=round(iso_achieved, 2), frac=round(iso_achieved / HBM_PEAK_GBS, 4),
+                      launches=int(k_n), traffic=prof.get("hbm_bytes_per_launch"),
+                      launch_shape="one launch alone on the chip: one stream, full grid (4 workgroups per CU); what a "
+                                   "synchronous call runs"),
+        valu=valu,
+        note="achieved = algorithmic_bytes_per_launch / kernel_us (the smaller, bit-packed byte count). The working set "
+             "(66 MB at config 3) sits in the 256 MiB Infinity Cache and the kernel is fp64-VALU bound: see roofline.valu",
     )
 
-    # ---- CPU baseline: plain-C OpenMP restatement on the host cores (rank 0, N=1 only) ----
+    # ---- CPU baselines on the host cores (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import abd_oracle as O
         from oracle import c_oracle
 
-        coh = O.Cohort(G, N, sc.vacs, sc.pcrpos, O.AntigenObs(sc.idx_gap, sc.idx_ind, sc.x_s, sc.y_s),
-                       O.AntigenObs(sc.idx_gap, sc.idx_ind, sc.x_n, sc.y_n))
+        def cohort_of(s):
+            return O.Cohort(s.n_gaps, s.n_inds, s.vacs, s.pcrpos, O.AntigenObs(s.idx_gap, s.idx_ind, s.x_s, s.y_s),
+                            O.AntigenObs(s.idx_gap, s.idx_ind, s.x_n, s.y_n))
+
+        def rate(fn, budget, max_n=20000):
+            n_done, t2 = 0, time.perf_counter()
+            while True:
+                fn(n_done)
+                n_done += 1
+                el = time.perf_counter() - t2
+                if el >= budget or n_done >= max_n:
+                    return n_done / el, n_done, el
+
+        coh = cohort_of(sc)
         co = c_oracle.COracle(coh, splits)
         # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only thrash
         cores = max(1, min(c_oracle.max_threads(), len(os.sched_getaffinity(0)), int(os.environ.get("ABD_CPU_THREADS", "16"))))
@@ -218,16 +307,25 @@ def main():
         scale = np.maximum(np.abs(g_c), 1e-6 * np.abs(g_c).max())
         if abs(lp_c - lp_all[0, 0]) > 1e-6 * abs(lp_c) or (np.abs(g_all[0, 0] - g_c) / scale).max() > 1e-6:
             raise SystemExit(f"bench parity check failed: gpu {lp_all[0, 0]} vs cpu {lp_c}")
-        n_done, t2 = 0, time.perf_counter()
-        while True:
-            co.logp_dlogp(thetas[W + (n_done % K), 0], i_raw, w, nthreads=cores)
-            n_done += 1
-            el = time.perf_counter() - t2
-            if el >= args.cpu_seconds or n_done >= 20000:
-                break
-        cpu = dict(value=round(n_done / el, 3), unit="evals/s", cores=cores, kind="port",
-                   sample=f"{n_done} logp+grad evals of chain 0 at fresh thetas on the same cohort ({el:.1f} s), "
-                          f"oracle/abd_oracle.c, OpenMP {cores} threads")
+        budget = args.cpu_seconds
+        v_n, n_n, el_n = rate(lambda k: co.logp_dlogp(thetas[W + (k % K), 0], i_raw, w, nthreads=cores), 0.5 * budget)
+        v_1, n_1, el_1 = rate(lambda k: co.logp_dlogp(thetas[W + (k % K), 0], i_raw, w, nthreads=1), 0.25 * budget)
+        # B0: the reference's algorithm as the reference states it -- dense (G, G, N) decay design, forward logp only
+        # (the reference adds reverse-mode autodiff over the same graph) -- at config 2, where it takes ~35 ms
+        sc2 = synthetic.make_cohort(CONFIGS["c2"]["n_inds"], CONFIGS["c2"]["n_gaps"])
+        coh2 = cohort_of(sc2)
+        i2, w2 = synthetic.make_chain_state(sc2.n_inds, sc2.n_gaps, 0)
+        th2 = synthetic.make_thetas(sc2.n_gaps, 1, 0)[0]
+        O.joint_logp(th2, i2, w2, coh2, dense=True)
+        v_b0, n_b0, el_b0 = rate(lambda k: O.joint_logp(th2, i2, w2, coh2, dense=True), 0.2 * budget, 200)
+        b0 = dict(value=round(v_b0, 3), unit="evals/s (forward logp only)", cores=1, config="c2: 1000 ind x 60 gaps",
+                  sample=f"{n_b0} evaluations in {el_b0:.1f} s, oracle/abd_oracle.py joint_logp(dense=True): the (G, G, N) form of abd.py:242-274",
+                  c3_recorded="4.0 s per forward evaluation at 10000 x 200 (3.2 GB of temporaries; tools/cpu_baselines.py on a GPU box, DESIGN.md section 5)")
+        cpu = dict(value=round(v_n, 3), unit="evals/s", cores=cores, kind="port",
+                   sample=f"{n_n} logp+grad evals of chain 0 at fresh thetas on the same cohort ({el_n:.1f} s), "
+                          f"oracle/abd_oracle.c, OpenMP {cores} threads",
+                   one_thread=dict(value=round(v_1, 3), unit="evals/s", cores=1, sample=f"{n_1} evals in {el_1:.1f} s, same code, 1 thread"),
+                   b0_reference_algorithm=b0)
 
     # ---- the whole compound step the path serves (informative; N=1 only): NUTS + Gibbs sweep, all chains in lock step
     compound = None
@@ -262,10 +360,18 @@ def main():
             "config": {"workload": cfg["name"], "n_inds": N, "n_gaps": G, "storage": cfg["storage"],
                        "chains_per_gpu": C, "total_chains": C * world, "splits": list(splits or ()),
                        "evals_per_step_per_gpu": C, "parallelism": f"chains sharded {C}/GPU x {world}"},
+            "value_kind": "stream-ordered: the K steps of a region are enqueued back to back at independent thetas and "
+                          "waited for once; sync_evals_per_s is the rate when every step is waited for",
+            "repeats": int(n_rep),
+            "region_ms": {"min": round(float(times.min()) * 1e3, 4), "median": round(elapsed * 1e3, 4),
+                          "max": round(float(times.max()) * 1e3, 4), "first": round(first * 1e3, 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "sync_evals_per_s": round(sync_rate, 1),
             "compound_step": compound,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+            "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                "device_of_rank0": device},
             "device": ctx.device_name,
         }
         print(json.dumps(line), flush=True)

@@ -228,12 +228,15 @@ int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* 
 int abd_theta_prior(abd_ctx* ctx, const double* theta, double* logp, double* grad);
 int abd_set_individual_offset(abd_ctx* ctx, int64_t first_individual);
 
-/* Measurement hooks used by bench.py: when enabled every evaluation kernel launch is bracketed by HIP
- * events on the stream it is launched on, and stream-ordered launches all go to ONE stream (normally they
- * alternate between two, so that the head of a launch overlaps the tail of the previous one: a launch's
- * own duration is only meaningful when nothing else is in flight).  abd_kernel_time returns the accumulated
- * kernel time and launch count since the last reset (synchronises). */
-int abd_kernel_timing(abd_ctx* ctx, int32_t enable);
+/* Measurement hooks used by bench.py.  mode 1: every evaluation kernel launch is bracketed by HIP events on
+ * the stream it is launched on, and stream-ordered launches all go to ONE stream with the full grid (normally
+ * they rotate over three, so that launches share the chip: a launch's own duration is only meaningful when
+ * nothing else is in flight) -- the isolated kernel.  mode 2: the launch shape is left alone and HIP events
+ * bracket every WINDOW of stream-ordered launches (first abd_logp_dlogp_batch_enqueue after an abd_wait ..
+ * every stream joined at the next abd_wait) -- device time per launch as a stream-ordered caller runs them.
+ * mode 0: off.  abd_kernel_time returns the accumulated device time and launch count since the last reset
+ * (synchronises). */
+int abd_kernel_timing(abd_ctx* ctx, int32_t mode);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* Tuning hook (benchmarks / experiments): number of 256-thread workgroups of the evaluation grid

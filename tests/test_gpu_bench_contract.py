@@ -10,23 +10,55 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True,
+                       timeout=timeout, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
 def test_bench_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "3", "--cpu-seconds", "2"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    d = _run(["--steps", "40", "--warmup", "3", "--cpu-seconds", "4"])
     assert d["metric"] == "logp+grad evals/sec" and d["unit"] == "evals/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["config"]["workload"].startswith("synthetic 10000 ind x 200 gaps") and "model" not in d["config"]
     assert d["value"] > 1e4 and abs(d["value"] - 40 * 4 / (d["ms_per_step"] * 40 / 1e3)) < 1e-3 * d["value"]
+    # the K-step region is repeated and the median reported
+    assert d["repeats"] >= 3 and d["region_ms"]["min"] <= d["region_ms"]["median"] <= d["region_ms"]["max"]
+    assert abs(d["region_ms"]["median"] - d["ms_per_step"] * 40) < 1e-3 * d["region_ms"]["median"]
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
     assert abs(ro["achieved"] - ro["algorithmic_bytes_per_launch"] / (ro["kernel_us"] * 1e-6) / 1e9) < 0.01 * ro["achieved"]
     assert ro["traffic"] is None or ro["traffic"] >= 0.9 * ro["algorithmic_bytes_per_launch"]
+    # the entry that carries frac describes the launch shape that was timed: its device time per launch cannot
+    # exceed the host's time per step (which adds the wait and the fetch)
+    assert ro["kernel_us"] <= d["ms_per_step"] * 1e3 * 1.02, (ro["kernel_us"], d["ms_per_step"])
+    assert ro["launches"] % 40 == 0
+    iso = ro["isolated"]
+    assert iso["kernel_us"] > 0 and abs(iso["frac"] - iso["achieved"] / 8000.0) < 1e-3 and iso["launches"] == 40
+    if ro["valu"] is not None:
+        assert ro["valu"]["peak"] == 78.6 and 0 < ro["valu"]["frac"] < 1.2
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "evals/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0
+    assert cb["b0_reference_algorithm"]["value"] > 0
     assert d["value"] > 20 * cb["value"]
+    assert d["sync_evals_per_s"] > 0 and d["dist"] is None
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE: two ranks (sharing this box's one GPU, gloo instead of RCCL)."""
+    env = {"ABD_DIST_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    d = _run(["--gpus", "2", "--steps", "30", "--warmup", "3", "--config", "c2", "--no-cpu-baseline"], env=env)
+    assert d["n_gpus"] == 2 and d["config"]["total_chains"] == 8 and d["steps"] == 30
+    assert d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo"
+    assert d["gather_ms"] is not None and d["gather_ms"] > 0
+    assert d["value"] > 0 and d["cpu_baseline"] is None

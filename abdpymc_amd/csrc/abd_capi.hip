@@ -91,6 +91,7 @@ struct abd_ctx {
   AntigenDev s, n;
   uint64_t* vw = nullptr;  // [nt][N]
   uint64_t* pw = nullptr;  // [nt][N]
+  double* exp2_tab = nullptr;  // dense cohorts: 2^(j/1024) (abd_dense.hpp)
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
   // A pipe = a HIP stream with its own pair of partial buffers and its own pending fixed-order sum.  Pipe 0 is
@@ -315,6 +316,7 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.yx_s = c->s.yx;
   a.vw = c->vw;
   a.pw = c->ignore_pcr ? nullptr : c->pw;
+  a.exp2_tab = c->exp2_tab;
   a.G = c->G;
   a.N = c->N;
   a.nt = c->nt;
@@ -323,9 +325,10 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   std::memcpy(a.chunk_mask, c->chunk_mask, sizeof a.chunk_mask);
 }
 
-size_t table_lds_bytes(int G, int cpw, int red_rows) {
+size_t table_lds_bytes(int G, int cpw, int red_rows, bool exp2_tab = false) {
   return std::max<size_t>(ABD_FIN_PARTS * ABD_NOUT * sizeof(double),  // finalize scratch of the fused form
-                          (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double));
+                          (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double) +
+                              (exp2_tab ? (size_t)ABD_EXP2_TAB * sizeof(double) : 0));
 }
 
 template <typename K>
@@ -439,7 +442,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
   } else if (c->dense) {
     blocks = dense_blocks(c, cpw, rotate, n / cpw);
-    lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK);
+    lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK, true);
   } else {
     blocks = c->blocks_x;
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);
@@ -701,6 +704,7 @@ void free_ctx(abd_ctx* c) {
   }
   if (c->vw) (void)hipFree(c->vw);
   if (c->pw) (void)hipFree(c->pw);
+  if (c->exp2_tab) (void)hipFree(c->exp2_tab);
   if (c->stage_gn) (void)hipFree(c->stage_gn);
   for (auto& s : c->slots) {
     if (s.rw) (void)hipFree(s.rw);
@@ -774,6 +778,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->n_chunks = d->n_splits + 1;
   c->storage = d->storage;
   c->dense = so_s.one_per_cell && so_n.one_per_cell;
+  // the dense kernel addresses the <= 34 gap rows of a chunk with a 32-bit scalar offset (abd_dense.hpp); beyond
+  // ~8 M individuals per GPU the cohort takes the observation-list kernels instead
+  if ((int64_t)N * (d->storage == ABD_STORE_F32 ? 8 : 16) * 34 >= ((int64_t)1 << 32)) c->dense = false;
   if (const char* e = std::getenv("ABD_FORCE_SPARSE"))
     if (std::atoi(e)) c->dense = false;
   c->ignore_pcr = d->pcrpos == nullptr;
@@ -827,7 +834,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->blocks_max = std::max({sparse_max, c->n_cu * 16, c->ob_n + c->ob_s + c->ob_c});
   c->dense_blocks = std::min(c->n_cu * dbpc, c->blocks_max);
   if (const char* e = std::getenv("ABD_CPW")) c->cpw_forced = std::atoi(e);
-  if (table_lds_bytes(G, 4, 16) > 160 * 1024) {
+  if (table_lds_bytes(G, 4, 16, true) > 160 * 1024) {
     free_ctx(c);
     return fail(ABD_ERR_ARG, "LDS tables for n_gaps=%d do not fit", G);
   }
@@ -852,6 +859,13 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     CREATE_TRY(hipMalloc(&c->pw, words * sizeof(uint64_t)));
     CREATE_TRY(hipMemcpy(c->vw, vw.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->pw, pw.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  if (c->dense) {
+    // 2^(j/1024) rounded once from the 64-bit-mantissa value
+    std::vector<double> tab(ABD_EXP2_TAB);
+    for (int j = 0; j < ABD_EXP2_TAB; ++j) tab[(size_t)j] = (double)exp2l((long double)j / (long double)ABD_EXP2_TAB);
+    CREATE_TRY(hipMalloc(&c->exp2_tab, tab.size() * sizeof(double)));
+    CREATE_TRY(hipMemcpy(c->exp2_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   CREATE_TRY(hipMalloc(&c->stage_gn, cells));
   c->slots.resize((size_t)c->n_slots);

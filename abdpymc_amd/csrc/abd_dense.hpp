@@ -10,30 +10,137 @@
 //
 // The 4 waves of a workgroup are CB chains x (4 / CB) neighbouring ranges: with CB = 4 the panel rows
 // they share are fetched from HBM once and served from L1/L2 to the other three.
+//
+// The kernel is bound by vector-instruction issue (fp64 instructions issue at half the rate of 32-bit ones),
+// so the gap loop is written for instruction count:
+//   * indicator bits -> 0.0 / 1.0 doubles by v_bfe_i32 (scalar bit index) + v_and with the high word of 1.0;
+//     the "exposed so far" flags of perm_response (abd.py:306) are integer ORs of those high words
+//   * e^u = 2^t with 1024 t = 1024 e + j + f: T[j] = 2^(j/1024) from a 1024-entry LDS table, a cubic in f,
+//     the exponent e added into T's high word; 1 + 2^t is ONE fma (tools/exp2_table.py: 3.5e-16)
+//   * one v_rcp_f64 per cell for both antigens (1/A = B/(AB))
+//   * gap rows are addressed as scalar row base + a constant per-lane offset (no vector address arithmetic)
 #pragma once
 
-// bits [g0, g0 + len) of the packed row, moved to bit 0 (len <= 64; g0 wave-uniform).  Every word is
-// visited with a compile-time index (a runtime-indexed register array would go to scratch).
-__device__ __forceinline__ uint64_t extract_bits(const uint64_t w[ABD_MAXT], int g0, int len) {
-  uint64_t v = 0;
+#define ABD_EXP2_TAB 1024  // entries of the 2^(j/1024) table (8 KB of LDS per workgroup)
+
+// bits [g0, g0 + 32) of the packed row, moved to bit 0 (g0 wave-uniform; bits past the row's end read as zero).
+// Every word is visited with a compile-time index (a runtime-indexed register array would go to scratch); the
+// uniform comparisons are scalar branches, the work is one v_alignbit_b32.
+__device__ __forceinline__ uint32_t extract_bits32(const uint64_t w[ABD_MAXT], int g0) {
+  const int idx = g0 >> 5;
+  const uint32_t sh = (uint32_t)g0 & 31u;
+  uint32_t v = 0;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
-    const int sh = g0 - t * 64;  // wave-uniform
-    if (sh >= 0 && sh < 64) v |= w[t] >> sh;
-    if (sh < 0 && sh > -64) v |= w[t] << (-sh);
+  for (int q = 0; q < 2 * ABD_MAXT; ++q) {
+    if (q == idx) {
+      const uint32_t lo = (q & 1) ? (uint32_t)(w[q >> 1] >> 32) : (uint32_t)w[q >> 1];
+      const uint32_t hi = q + 1 < 2 * ABD_MAXT ? (((q + 1) & 1) ? (uint32_t)(w[(q + 1) >> 1] >> 32) : (uint32_t)w[(q + 1) >> 1]) : 0u;
+      v = __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
   }
-  return len >= 64 ? v : (v & ((1ull << len) - 1ull));
+  return v;
+}
+
+// One {od, log_dilution} pair of a gap row: buffer load with a scalar row offset and a constant per-lane offset.
+typedef uint32_t abd_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t abd_u32x2 __attribute__((ext_vector_type(2)));
+template <typename R>
+__device__ __forceinline__ YX<R> load_yx(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff);
+template <>
+__device__ __forceinline__ YX<double> load_yx<double>(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff) {
+  const abd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  YX<double> r;
+  r.y = __hiloint2double((int)v.y, (int)v.x);
+  r.x = __hiloint2double((int)v.w, (int)v.z);
+  return r;
+}
+template <>
+__device__ __forceinline__ YX<float> load_yx<float>(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff) {
+  const abd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  YX<float> r;
+  r.y = __uint_as_float(v.x);
+  r.x = __uint_as_float(v.y);
+  return r;
+}
+
+// the double whose high word is `hi` and whose low word is `zero` (a register that holds 0; 0.0 and 1.0 are such
+// doubles).  Each stream of such doubles gets its own zero register (zero_vgpr), so that the register pair is
+// {that register, hi} and the high word is computed in place -- with a shared literal 0 the compiler copies it
+// into the low half of every new pair, one v_mov_b32 per double per gap.
+__device__ __forceinline__ double hi_to_double(uint32_t hi, uint32_t zero) { return __hiloint2double((int)hi, (int)zero); }
+__device__ __forceinline__ uint32_t zero_vgpr() {
+  uint32_t z = 0;
+  asm volatile("" : "+v"(z));
+  return z;
+}
+// rho * x + y with a scalar rho as ONE three-address v_fma_f64 (left to itself the compiler picks the two-address
+// v_fmac_f64 for the loop-carried recurrences and pays a v_mov_b64 to keep the old value)
+__device__ __forceinline__ double fma_s(double rho_sgpr, double x, double y) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(rho_sgpr), "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ double fma_v(double rho_vgpr, double x, double y) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(rho_vgpr), "v"(x), "v"(y));
+  return r;
+}
+
+// 1 + 2^(t1024 / 1024).  kf = rint(t1024), f = t1024 - kf exact; v_cvt_i32_f64 saturates, so any finite t1024 gives
+// a finite result (the exponent is clamped to [-1022, 510]: 2^510 keeps the product of the two antigens' terms
+// finite, below 2^-1022 the term is 1 anyway); NaN stays NaN.
+__device__ __forceinline__ double one_plus_exp2_tab(double t1024, const double* tab /* LDS */) {
+  const double kf = __builtin_rint(t1024);
+  const double f = t1024 - kf;
+  int k;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(kf));  // saturating; a C++ cast of an out-of-range double is undefined
+  const double T = tab[k & (ABD_EXP2_TAB - 1)];
+  const int e = min(max(k >> 10, -1022), 510);  // v_med3_i32
+  const double Ts = __hiloint2double(__double2hiint(T) + (e << 20), __double2loint(T));  // T 2^e: v_lshl_add_u32
+  double p = fma(0x1.c6b08d910ecbdp-35, f, 0x1.ebfbe033445b4p-23);  // tools/exp2_table.py 1024 3
+  p = fma(p, f, 0x1.62e42fefa39efp-11);
+  p = fma(p, f, 1.0);
+  return fma(Ts, p, 1.0);
+}
+static_assert(ABD_EXP2_TAB == 1024, "one_plus_exp2_tab: k >> 10 and the polynomial assume 1024 entries");
+
+// Both antigens of one cell at once: the two reciprocals 1/(1+e_n), 1/(1+e_s) come from ONE v_rcp_f64 (quarter
+// rate) of the product -- 1/A = B/(AB), 1/B = A/(AB).  c_n = b_n log2(e) 1024, c_s likewise (wave-uniform).
+template <bool GRAD>
+__device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, double c_n, double d_n, double as, double xs,
+                                             double ys, double c_s, double d_s, const double* tab, double (&acc)[16],
+                                             double& h_n, double& h_s) {
+  const double amx_n = an - xn, amx_s = as - xs;
+  const double A = one_plus_exp2_tab(c_n * amx_n, tab);
+  const double B = one_plus_exp2_tab(c_s * amx_s, tab);
+  const double r = rcp_newton(A * B);
+  const double s_n = r * B, s_s = r * A;  // logistic / d
+  const double q_n = fma(-d_n, s_n, yn), q_s = fma(-d_s, s_s, ys);
+  acc[A_N_Q2] = fma(q_n, q_n, acc[A_N_Q2]);
+  acc[A_S_Q2] = fma(q_s, q_s, acc[A_S_Q2]);
+  if (GRAD) {
+    const double u_n = q_n * s_n, u_s = q_s * s_s;
+    acc[A_N_QS] += u_n;
+    acc[A_S_QS] += u_s;
+    h_n = fma(-u_n, s_n, u_n);  // q s (1 - s)
+    h_s = fma(-u_s, s_s, u_s);
+    acc[A_N_H] += h_n;
+    acc[A_S_H] += h_s;
+    acc[A_N_HX] = fma(h_n, amx_n, acc[A_N_HX]);
+    acc[A_S_HX] = fma(h_s, amx_s, acc[A_S_HX]);
+  }
 }
 
 template <typename R, int CB, bool GRAD>
 __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
-  // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction
+  // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction, 2^(j/1024) table
   extern __shared__ __align__(16) unsigned char smem[];
   const int G = a.G, N = a.N, nt = a.nt;
   const int tstride = G + 1;
   double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   double2_t* tab_ones = tabs + CB * 2 * tstride;
   double* red = reinterpret_cast<double*>(tab_ones + tstride);  // [WAVES][ABD_NOUT]
+  double* tab_e2 = red + ABD_WAVES_PER_BLOCK * ABD_NOUT;           // [ABD_EXP2_TAB] 2^(j/1024)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,6 +191,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
   }
   if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, n_entries, lane);
+  for (int e = tid; e < ABD_EXP2_TAB; e += ABD_BLOCK) tab_e2[e] = a.exp2_tab[e];
 
   double acc[16];
 #pragma unroll
@@ -94,7 +202,8 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   // VGPRs, or every use costs a v_mov_b64
   const double init_n = to_vgpr(p.init_n), init_s = to_vgpr(p.init_s);
   const double perm_n = p.perm_n, perm_s = p.perm_s;
-  const double b_n = p.b_n, d_n = p.d_n, b_s = p.b_s, d_s = p.d_s;
+  const double d_n = p.d_n, d_s = p.d_s;
+  const double c_n = p.b_n * (1.4426950408889634074 * ABD_EXP2_TAB), c_s = p.b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
   const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
   const double2_t* tab_sw = tabs + (c * 2 + 1) * tstride;
   __syncthreads();
@@ -133,7 +242,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
 
     // state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures
     double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
-    double cf_n = 0.0, cf_s = 0.0;                   // exposure-so-far flags as 0.0 / 1.0 (abd.py:306)
+    uint32_t cfn_hi = 0, cfs_hi = 0;                 // exposure-so-far flags (abd.py:306): high word of 0.0 / 1.0
     if (g0 > 0) {
       const double2_t* tab_s = wj ? tab_sw : tab_ones;
 #pragma unroll
@@ -142,8 +251,8 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
           const int rel = g0 - t * 64;  // bits < rel of word t are before the piece
           const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
           uint64_t mi = I[t] & below, mv = V[t] & below;
-          if (mi != 0) cf_n = 1.0;
-          if ((mi | mv) != 0) cf_s = 1.0;
+          if (mi != 0) cfn_hi = 0x3FF00000u;
+          if ((mi | mv) != 0) cfs_hi = 0x3FF00000u;
           while (mi) {  // per-lane trip count
             const int b = __builtin_ctzll(mi);
             mi &= mi - 1;
@@ -169,31 +278,40 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     // ---- walk the piece: recurrence form (abd.py:288) + likelihood terms ----
     const double rho_j = wj ? rho_s : 1.0;  // abd.py:374
     double hd_s = 0.0;
-    for (int gc = g0; gc < g1; gc += 64) {  // <= 64 gaps of indicator bits at a time
-      const int len = min(64, g1 - gc);
-      uint64_t seg_i = extract_bits(I, gc, len);
-      uint64_t seg_v = extract_bits(V, gc, len);
-      // gap rows: wave-uniform base + this lane's individual
-      const YX<R>* row_n = reinterpret_cast<const YX<R>*>(a.yx_n) + (int64_t)gc * N;
-      const YX<R>* row_s = reinterpret_cast<const YX<R>*>(a.yx_s) + (int64_t)gc * N;
+    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
+    const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // 34 rows of it fit 32 bits (abd_create checks)
+    const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
+    for (int gc = g0; gc < g1; gc += 32) {  // <= 32 gaps of indicator bits at a time
+      const int len = min(32, g1 - gc);
+      const uint32_t seg_i = extract_bits32(I, gc);
+      const uint32_t seg_v = extract_bits32(V, gc);
+      // gap rows through buffer loads: descriptor base = this chunk's first row of this lane group (scalar), scalar
+      // offset = row within the chunk, vector offset = the lane's constant -- no vector address arithmetic at all
+      const int64_t row0 = ((int64_t)gc * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
+      const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.yx_n)) + row0, 0, -1, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.yx_s)) + row0, 0, -1, 0x00020000);
+      auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int gi) { return load_yx<R>(rs, lane_off, (uint32_t)gi * rstride); };
 
       // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
-      auto step = [&](const YX<R>& on, const YX<R>& os) {
-        const uint32_t ib = (uint32_t)seg_i & 1u, vb = (uint32_t)seg_v & 1u;
-        seg_i >>= 1;
-        seg_v >>= 1;
-        const double e_i = (double)ib, e_v = (double)vb;
-        dn = fma(rho_n, dn, tn);
-        tn = fma(rho_n, tn, e_i);
-        ds = fma(rho_j, ds, ts);
-        ts = fma(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
-        cf_n = fmax(cf_n, e_i);
-        cf_s = fmax(cf_s, fmax(e_i, e_v));
+      auto step = [&](int gi, const YX<R>& on, const YX<R>& os) {
+        const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, (uint32_t)gi, 1u) & 0x3FF00000u;
+        const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, (uint32_t)gi, 1u) & 0x3FF00000u;
+        const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
+        cfn_hi |= ei_hi;
+        cfs_hi |= ei_hi | ev_hi;
+        dn = fma_s(rho_n, dn, tn);
+        tn = fma_s(rho_n, tn, e_i);
+        ds = fma_v(rho_j, ds, ts);
+        ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
+        const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
         // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
         const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
         const double as = fma(cf_s, perm_s, init_s) + ts;
         double h_n = 0.0, h_s = 0.0;
-        obs_pair<GRAD>(an, (double)on.x, (double)on.y, b_n, d_n, as, (double)os.x, (double)os.y, b_s, d_s, acc, h_n, h_s);
+        obs_pair_tab<GRAD>(an, (double)on.x, (double)on.y, c_n, d_n, as, (double)os.x, (double)os.y, c_s, d_s, tab_e2, acc,
+                           h_n, h_s);
         if (GRAD) {
           acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
           acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
@@ -205,19 +323,19 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
 
       // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
       const int last = len - 1;
-      YX<R> n0 = row_n[j], s0 = row_s[j];
-      YX<R> n1 = row_n[(int64_t)min(1, last) * N + j], s1 = row_s[(int64_t)min(1, last) * N + j];
+      YX<R> n0 = ldrow(rs_n, 0), s0 = ldrow(rs_s, 0);
+      YX<R> n1 = ldrow(rs_n, min(1, last)), s1 = ldrow(rs_s, min(1, last));
       int gi = 0;
       for (; gi + 1 < len; gi += 2) {
         const int ga = min(gi + 2, last), gb = min(gi + 3, last);
-        step(n0, s0);
-        n0 = row_n[(int64_t)ga * N + j];
-        s0 = row_s[(int64_t)ga * N + j];
-        step(n1, s1);
-        n1 = row_n[(int64_t)gb * N + j];
-        s1 = row_s[(int64_t)gb * N + j];
+        step(gi, n0, s0);
+        n0 = ldrow(rs_n, ga);
+        s0 = ldrow(rs_s, ga);
+        step(gi + 1, n1, s1);
+        n1 = ldrow(rs_n, gb);
+        s1 = ldrow(rs_s, gb);
       }
-      if (gi < len) step(n0, s0);
+      if (gi < len) step(gi, n0, s0);
     }
     acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
     }  // j < N

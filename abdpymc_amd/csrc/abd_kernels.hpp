@@ -86,6 +86,7 @@ struct EvalArgs {
   // packed indicator panels [nt][N]
   const uint64_t* vw;
   const uint64_t* pw;  // nullptr = ignore_pcrpos
+  const double* exp2_tab;  // dense kernel: 2^(j/1024), j = 0..1023, correctly rounded (copied to LDS per workgroup)
   double* partials;    // [n_chains][grid.x][ABD_NOUT]
   // dense kernel only: the fixed-order sum of the PREVIOUS launch's partials, done by the first
   // prev_n_chains workgroups of this launch (saves a kernel and a boundary per step when launches are

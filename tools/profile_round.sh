@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the evidence bench.py's numbers rest on, on ONE GPU box: usage tools/profile_round.sh OUTDIR [configs...]
+# (run from the repo root; writes under OUTDIR, which should be below gpurun_out/).  Every rocprofv3 command puts
+# the program itself after "--" (python3 <script>); counters are collected in their own passes.
+set -u
+OUT=${1:-gpurun_out/prof}; shift || true
+CFGS=${*:-c3}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ROOT=$PWD
+summ() { python3 tools/pmc_summary.py "$1" abd_ > "$2" 2>&1; }
+for cfg in $CFGS; do
+  case $cfg in
+    c3) SW="--n-inds 10000 --n-gaps 200 --chains 4 --storage f64 --cpw 4 --blocks 1024,256" ;;
+    c2) SW="--n-inds 1000 --n-gaps 60 --chains 4 --storage f64 --cpw 4 --blocks 0" ;;
+    c5) SW="--n-inds 100000 --n-gaps 200 --chains 1 --storage f32 --cpw 1 --blocks 0,256" ;;
+  esac
+  echo "== $cfg: bench line" ; python3 bench.py --config $cfg > "$OUT/${cfg}_bench.json" 2> "$OUT/${cfg}_bench.err" || { echo bench failed; tail -5 "$OUT/${cfg}_bench.err"; exit 1; }
+  echo "== $cfg: kernel trace of the same command"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace" -- python3 bench.py --config $cfg --no-cpu-baseline > "$OUT/${cfg}_bench_under_rocprof.json" 2> "$OUT/${cfg}_trace.err" || { echo trace failed; tail -5 "$OUT/${cfg}_trace.err"; exit 1; }
+  find "$OUT/${cfg}_trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/${cfg}_kernel_stats.csv" \;
+  echo "== $cfg: isolated kernel (ABD_PIPES=1)"
+  ABD_PIPES=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace1" -- python3 bench.py --config $cfg --no-cpu-baseline > "$OUT/${cfg}_bench_one_pipe_under_rocprof.json" 2> "$OUT/${cfg}_trace1.err" || { echo trace1 failed; exit 1; }
+  find "$OUT/${cfg}_trace1" -name "*kernel_stats.csv" -exec cp {} "$OUT/${cfg}_one_pipe_kernel_stats.csv" \;
+  echo "== $cfg: PMC passes over tools/sweep.py $SW"
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$OUT/${cfg}_pmc_sq" --output-format csv -- python3 tools/sweep.py $SW --iters 10 > "$OUT/${cfg}_pmc_sq.log" 2>&1 || { echo pmc sq failed; tail -5 "$OUT/${cfg}_pmc_sq.log"; exit 1; }
+  summ "$OUT/${cfg}_pmc_sq" "$OUT/${cfg}_pmc_sq.txt"
+  rocprofv3 --pmc FETCH_SIZE -d "$OUT/${cfg}_pmc_fetch" --output-format csv -- python3 tools/sweep.py $SW --iters 10 > "$OUT/${cfg}_pmc_fetch.log" 2>&1 || { echo pmc fetch failed; exit 1; }
+  summ "$OUT/${cfg}_pmc_fetch" "$OUT/${cfg}_pmc_fetch_size.txt"
+  rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/${cfg}_pmc_write" --output-format csv -- python3 tools/sweep.py $SW --iters 10 > "$OUT/${cfg}_pmc_write.log" 2>&1 || { echo pmc write failed; exit 1; }
+  summ "$OUT/${cfg}_pmc_write" "$OUT/${cfg}_pmc_write_size_l2.txt"
+  rm -rf "$OUT/${cfg}_trace" "$OUT/${cfg}_trace1" "$OUT/${cfg}_pmc_sq" "$OUT/${cfg}_pmc_fetch" "$OUT/${cfg}_pmc_write"
+done
+ls -la "$OUT"

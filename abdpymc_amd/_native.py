@@ -121,6 +121,7 @@ SYMBOLS = {
     "abd_kernel_time": (C.c_int, [_P, _D, C.POINTER(C.c_int64), C.c_int32]),
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
+    "abd_wait_fallbacks": (C.c_int64, [_P]),
     "abd_is_dense": (C.c_int, [_P]),
 }
 
@@ -236,6 +237,10 @@ class Context:
             d.pcrpos = _ptr(p8, C.c_int8)
         _check(lib, lib.abd_create(C.byref(d), C.byref(self._h)))
         self.n_result_slots = lib.abd_n_result_slots(self._h)
+        # one counter per chain slot, bumped by everything that rewrites the slot's device-side discrete state
+        # (set_discrete, flip_discrete, gibbs_sweep, the native sampler): host mirrors of that state (DiscreteMirror)
+        # are only trusted while the counter stands where they left it
+        self._generation = [0] * self.n_chains
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -262,10 +267,23 @@ class Context:
     def is_dense(self) -> bool:
         return bool(self._lib.abd_is_dense(self._h))
 
+    @property
+    def wait_fallbacks(self) -> int:
+        """Synchronous calls that had to fall back from the polled completion tag to a stream synchronise (expect 0)."""
+        return int(self._lib.abd_wait_fallbacks(self._h))
+
     def algorithmic_bytes(self, n_chains: int) -> int:
         return int(self._lib.abd_algorithmic_bytes(self._h, n_chains))
 
     # -- discrete state -----------------------------------------------------------------------
+    def generation(self, chain: int) -> int:
+        """Changes every time the slot's device-side (i_raw, ab_s_waner) is rewritten by anyone."""
+        return self._generation[int(chain)]
+
+    def _bump(self, chains):
+        for c in np.atleast_1d(chains):
+            self._generation[int(c)] += 1
+
     def set_discrete(self, chain: int, i_raw, waner):
         i_raw, waner = np.asarray(i_raw), np.asarray(waner)
         if i_raw.shape != (self.n_gaps, self.n_inds):
@@ -276,9 +294,11 @@ class Context:
         if not (np.array_equal(i8, i_raw) and np.array_equal(w8, waner)):
             raise ValueError("i_raw / ab_s_waner must be 0/1")
         _check(self._lib, self._lib.abd_set_discrete(self._h, chain, _ptr(i8, C.c_int8), _ptr(w8, C.c_int8)))
+        self._bump(chain)
 
     def flip_discrete(self, chain: int, flat: int):
         _check(self._lib, self._lib.abd_flip_discrete(self._h, chain, int(flat)))
+        self._bump(chain)
 
     def get_discrete(self, chain: int):
         i = np.empty((self.n_gaps, self.n_inds), dtype=np.int8)
@@ -294,6 +314,7 @@ class Context:
             raise ValueError(f"theta must have shape ({ch.size}, {N_THETA})")
         acc = np.zeros(ch.size, dtype=np.int64)
         prop = np.zeros(ch.size, dtype=np.int64)
+        self._bump(ch)
         _check(self._lib, self._lib.abd_gibbs_sweep(self._h, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double),
                                                     C.c_uint64(seed & (2**64 - 1)), C.c_uint32(sweep & 0xFFFFFFFF),
                                                     _ptr(acc, C.c_int64), _ptr(prop, C.c_int64)))
@@ -419,6 +440,55 @@ class Context:
         return ms.value, n.value
 
 
+class DiscreteMirror:
+    """
+    Host mirror of ONE chain slot's device-side ``(i_raw, ab_s_waner)``, for callers that are handed the whole
+    discrete state on every call (``Model.compile_logp()``'s point function under BinaryGibbsMetropolis, a PyTensor
+    ``Op.perform``): ``update`` uploads only what changed -- nothing, a few ``abd_flip_discrete`` calls, or the whole
+    panel.  The mirror is trusted only while the slot's generation counter (``Context.generation``) stands where
+    this mirror left it: anything else that rewrites the slot (another callable's ``set_discrete``, a device Gibbs
+    sweep, the native sampler) bumps the counter and the next ``update`` re-uploads.
+    """
+
+    MAX_FLIPS = 8
+
+    def __init__(self, ctx: "Context", chain: int = 0):
+        self.ctx, self.chain = ctx, int(chain)
+        self._state = None
+        self._gen = None
+        self.uploads = self.flips = self.hits = 0  # what update() did so far (tests, profiling)
+
+    def invalidate(self):
+        self._state = None
+
+    def update(self, i_raw, waner):
+        ctx, c = self.ctx, self.chain
+        i_raw, waner = np.asarray(i_raw), np.asarray(waner)
+        prev = self._state
+        if prev is not None and self._gen == ctx.generation(c) and prev[0].shape == i_raw.shape and prev[1].shape == waner.shape:
+            if i_raw is prev[2] and waner is prev[3] and not (i_raw.flags.writeable or waner.flags.writeable):
+                self.hits += 1  # the very same read-only arrays: nothing can have changed
+                return
+            di = np.flatnonzero(i_raw.ravel() != prev[0].ravel())
+            dw = np.flatnonzero(waner != prev[1])
+            if di.size + dw.size == 0:
+                self.hits += 1
+                return
+            if di.size + dw.size <= self.MAX_FLIPS:
+                for f in di:
+                    ctx.flip_discrete(c, int(f))
+                for f in dw:
+                    ctx.flip_discrete(c, int(i_raw.size + f))
+                self.flips += int(di.size + dw.size)
+                self._state = (i_raw.copy(), waner.copy(), i_raw, waner)
+                self._gen = ctx.generation(c)
+                return
+        ctx.set_discrete(c, i_raw, waner)
+        self.uploads += 1
+        self._state = (i_raw.copy(), waner.copy(), i_raw, waner)
+        self._gen = ctx.generation(c)
+
+
 class NativeSampler:
     """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922), one launch per lock-step leapfrog."""
 
@@ -432,6 +502,7 @@ class NativeSampler:
         if t0.shape != (ch.size, N_THETA):
             raise ValueError(f"theta0 must have shape ({ch.size}, {N_THETA})")
         self.n = int(ch.size)
+        self._chains = ch.copy()
         o = _SamplerOpts()
         o.tune, o.seed = int(tune), int(seed) & (2**64 - 1)
         o.target_accept, o.max_treedepth = float(target_accept), int(max_treedepth)
@@ -446,6 +517,7 @@ class NativeSampler:
         """Advance all chains by n_iter iterations -> theta (n, n_iter, 17), stats {name: (n, n_iter)}."""
         theta = np.empty((self.n, n_iter, N_THETA))
         stats = np.empty((self.n, n_iter, N_STATS))
+        self._ctx._bump(self._chains)  # the sweeps rewrite the chains' discrete state
         _check(self._lib, self._lib.abd_sampler_run(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double)))
         return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}
 
@@ -472,6 +544,7 @@ class NativeSampler:
         rec.capacity, rec.first = int(cap or 0), int(first)
         theta = np.empty((self.n, n_iter, N_THETA))
         stats = np.empty((self.n, n_iter, N_STATS))
+        self._ctx._bump(self._chains)
         _check(self._lib, self._lib.abd_sampler_run_record(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double),
                                                            C.byref(rec)))
         return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}

@@ -28,7 +28,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--ignore_pcrpos", help="Ignore PCR+ data", action="store_true")
     parser.add_argument("--netcdf", help="Path of netCDF file to save.")
     # additions (all optional)
-    parser.add_argument("--chains", help="Number of chains (default: --cores or 1).", type=int)
+    parser.add_argument("--chains", help="Number of chains (default: as pm.sample -- max(2, cores), cores = --cores or "
+                        "min(4, CPU count)).", type=int)
     parser.add_argument("--seed", help="Random seed.", type=int, default=0)
     parser.add_argument("--device", help="HIP device ordinal.", type=int, default=-1)
     parser.add_argument("--no_deterministics", help="Do not record i / ab_n_mu / ab_s_mu per draw.", action="store_true")
@@ -71,10 +72,17 @@ def main(argv=None) -> int:
         if (not args.split_delta) and (not args.split_omicron)
         else data.calculate_splits(delta=args.split_delta, omicron=args.split_omicron)
     )  # abd.py:915-919
-    chains = args.chains or args.cores or 1
+    # pm.sample(cores=...) (abd.py:922) runs chains = max(2, cores) with cores = min(4, CPU count) when not given
+    import os
+
+    cores = args.cores or min(4, os.cpu_count() or 1)
+    chains = args.chains or max(2, cores)
     counts = distributed.split_counts(chains, world)
     mine, first = counts[rank], sum(counts[:rank])
-    if mine == 0:
+    if chains < world:
+        # every rank sees the same numbers and leaves together (a rank that went on alone would hang in the gather)
+        if dist is not None:
+            dist.destroy_process_group()
         raise SystemExit(f"{chains} chains cannot be sharded over {world} processes: fewer chains than ranks")
     device = args.device
     if world > 1 and device < 0:

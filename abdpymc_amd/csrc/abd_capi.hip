@@ -136,6 +136,7 @@ struct abd_ctx {
   size_t ev_used = 0;
   double ev_total_ms = 0.0;
   int64_t ev_count = 0;
+  int64_t wait_fallbacks = 0;  // synchronous calls whose completion tag never showed and that fell back to a stream synchronise
   char name[256] = {0};
 };
 
@@ -551,6 +552,9 @@ int wait_rows(abd_ctx* c, int slot, int n, double tag) {
     }
     __builtin_ia32_pause();
   }
+  // the tag did not show within ~2 M polls (tens of ms): not an error -- the stream synchronise below is always
+  // correct -- but it should never happen, so it is counted (abd_wait_fallbacks) instead of passing as a slow call
+  c->wait_fallbacks++;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
 }
@@ -1200,6 +1204,8 @@ int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t res
   }
   return ABD_OK;
 }
+
+int64_t abd_wait_fallbacks(abd_ctx* c) { return c ? c->wait_fallbacks : -1; }
 
 int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   if (!c) return 0;

@@ -103,11 +103,14 @@ class ValueGradFunction:
         self._chain = chain
         self._extra_are_set = False
         self._extra_vars_shared: Dict[str, np.ndarray] = {}
+        self._mirror = _native.DiscreteMirror(model.ctx, chain)
 
     def set_extra_values(self, point: Dict[str, np.ndarray]) -> None:
         i_raw = np.asarray(point["i_raw"])
         waner = np.asarray(point["ab_s_waner"])
-        self._model.ctx.set_discrete(self._chain, i_raw, waner)
+        # uploads what changed since this callable last looked -- unless someone else (the point function of
+        # compile_logp(), a device sweep) has rewritten the slot meanwhile: then the whole state goes up again
+        self._mirror.update(i_raw, waner)
         self._extra_vars_shared = {"i_raw": i_raw.copy(), "ab_s_waner": waner.copy()}
         self._extra_are_set = True
 
@@ -224,30 +227,17 @@ class AbdModel:
     def compile_logp(self, chain: int = 0):
         """``logp_fn(point: dict) -> float64``: the PointFunc BinaryGibbsMetropolis calls once per flipped bit."""
         ctx = self.ctx
-        last = {}
+        mirror = _native.DiscreteMirror(ctx, chain)
 
         def logp_fn(point: Dict[str, np.ndarray]) -> np.float64:
-            i_raw = np.asarray(point["i_raw"])
-            waner = np.asarray(point["ab_s_waner"])
-            prev = last.get("state")
-            if prev is None:
-                ctx.set_discrete(chain, i_raw, waner)
-            else:
-                # a Gibbs step changes one raveled bit between calls: flip it on the device instead of
-                # re-uploading the panel
-                di = np.flatnonzero(i_raw.ravel() != prev[0].ravel())
-                dw = np.flatnonzero(waner != prev[1])
-                if di.size + dw.size <= 8:
-                    for f in di:
-                        ctx.flip_discrete(chain, int(f))
-                    for f in dw:
-                        ctx.flip_discrete(chain, int(i_raw.size + f))
-                else:
-                    ctx.set_discrete(chain, i_raw, waner)
-            last["state"] = (i_raw.copy(), waner.copy())
+            # a Gibbs step changes one raveled bit between calls: the mirror flips it on the device instead of
+            # re-uploading the panel, and re-uploads when anything else has touched the slot since (the slot's
+            # generation counter: ValueGradFunction.set_extra_values, gibbs_sweep, the native sampler)
+            mirror.update(point["i_raw"], point["ab_s_waner"])
             return np.float64(ctx.logp(chain, self.ravel(point)))
 
-        logp_fn.invalidate = lambda: last.clear()
+        logp_fn.invalidate = mirror.invalidate
+        logp_fn.mirror = mirror
         return logp_fn
 
     def logp_dlogp_function(self, chain: int = 0) -> ValueGradFunction:

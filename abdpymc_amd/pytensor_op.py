@@ -32,6 +32,7 @@ class _Lazy:
     def __init__(self, data, splits, ignore_pcrpos):
         self.data, self.splits, self.ignore_pcrpos = data, splits, ignore_pcrpos
         self._model = None
+        self._mirror = None
 
     def model(self):
         if self._model is None:
@@ -40,8 +41,24 @@ class _Lazy:
             self._model = AbdModel(self.data, self.splits, self.ignore_pcrpos, n_chains=1)
         return self._model
 
+    def mirror(self):
+        """Host mirror of chain slot 0's discrete state: NUTS leapfrogs never change it, a Gibbs proposal changes
+        one bit -- ``perform`` uploads only the difference (see _native.DiscreteMirror)."""
+        if self._mirror is None:
+            from ._native import DiscreteMirror
+
+            self._mirror = DiscreteMirror(self.model().ctx, 0)
+        return self._mirror
+
+    def loglik_dlogp_constrained(self, params, i_raw, waner):
+        """What ``AbdDataLogp.perform`` computes: the data term and its gradient w.r.t. the 13 constrained parameters."""
+        m = self.model()
+        self.mirror().update(np.asarray(i_raw), np.asarray(waner))
+        ll, g = m.ctx.loglik_dlogp(0, _theta_from_constrained(params, m.n_gaps))  # data term only; PyMC keeps the priors
+        return ll, _grad_to_constrained(g, params)
+
     def __getstate__(self):
-        return dict(data=self.data, splits=self.splits, ignore_pcrpos=self.ignore_pcrpos, _model=None)
+        return dict(data=self.data, splits=self.splits, ignore_pcrpos=self.ignore_pcrpos, _model=None, _mirror=None)
 
 
 if HAVE_PYMC:  # pragma: no cover
@@ -65,12 +82,9 @@ if HAVE_PYMC:  # pragma: no cover
 
         def perform(self, node, inputs, output_storage):
             params, i_raw, waner = inputs
-            m = self.lazy.model()
-            theta = _theta_from_constrained(params, m.n_gaps)
-            m.ctx.set_discrete(0, np.asarray(i_raw, dtype=np.int8), np.asarray(waner, dtype=np.int8))
-            ll, g = m.ctx.loglik_dlogp(0, theta)  # data term only; PyMC keeps the priors
+            ll, g = self.lazy.loglik_dlogp_constrained(params, i_raw, waner)
             output_storage[0][0] = np.asarray(ll)
-            output_storage[1][0] = _grad_to_constrained(g, params)
+            output_storage[1][0] = g
 
         def grad(self, inputs, output_grads):
             params, i_raw, waner = inputs

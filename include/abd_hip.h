@@ -237,6 +237,10 @@ int abd_set_individual_offset(abd_ctx* ctx, int64_t first_individual);
  * mode 0: off.  abd_kernel_time returns the accumulated device time and launch count since the last reset
  * (synchronises). */
 int abd_kernel_timing(abd_ctx* ctx, int32_t mode);
+/* Synchronous calls wait for their result rows by polling a completion tag in mapped host memory; if a tag does not
+ * show within ~2 M polls the call falls back to a stream synchronise (still correct).  Number of such fall-backs
+ * since abd_create: anything but 0 means the tag path has regressed. */
+int64_t abd_wait_fallbacks(abd_ctx* ctx);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* Tuning hook (benchmarks / experiments): number of 256-thread workgroups of the evaluation grid

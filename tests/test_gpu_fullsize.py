@@ -4,7 +4,7 @@ BASELINE.json's configurations at full size, on the GPU, through the C ABI:
   config 3  synthetic 10 000 x 200, fp64, 4 chains -- against the plain-C port (OpenMP) and through
             size-independent properties: the data term is additive over individuals (two half cohorts sum to
             the whole), a batched launch equals four single launches, results do not depend on the grid
-  config 5 (one GPU's share, reduced to 20 000 x 200 to keep the test short) fp32 storage
+  config 5  one GPU's share at full size: 100 000 x 200, fp32 storage, 1 chain (and a 20 000 x 200 case)
 """
 import numpy as np
 import pytest
@@ -118,3 +118,45 @@ def test_config5_fp32_storage_20000x200():
     co64 = c_oracle.COracle(coh)
     lp64, _ = co64.logp_dlogp(theta, i_raw, w, nthreads=8)
     assert abs(lp - lp64) <= 1e-4 * abs(lp64)  # storage rounding only: tolerance 1e-4 relative, stated
+
+
+def test_config5_full_size_100000x200_fp32():
+    """BASELINE config 5 at its real size -- one GPU's share: 100 000 x 200, fp32 storage, 1 chain (330 MB of panels,
+    beyond the 256 MiB Infinity Cache): against the plain-C port on the fp32-rounded panels, and additive over two
+    unequal parts of the cohort."""
+    N, G = 100000, 200
+    sc = synthetic.make_cohort(N, G)
+    coh = oracle_cohort_from_synth(sc)
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)  # noqa: E731
+    coh32 = O.Cohort(coh.n_gaps, coh.n_inds, coh.vacs, coh.pcrpos,
+                     O.AntigenObs(coh.s.idx_gap, coh.s.idx_ind, r32(coh.s.log_dilution), r32(coh.s.od)),
+                     O.AntigenObs(coh.n.idx_gap, coh.n.idx_ind, r32(coh.n.log_dilution), r32(coh.n.od)))
+    i_raw, w = synthetic.make_chain_state(N, G, 0)
+    thetas = synthetic.make_thetas(G, 2, 0)
+    ctx = _ctx(sc, 1, storage="f32")
+    assert ctx.is_dense
+    ctx.set_discrete(0, i_raw, w)
+    co = c_oracle.COracle(coh32)
+    for theta in thetas:
+        lp, g = ctx.logp_dlogp(0, theta)
+        _close(lp, g, *co.logp_dlogp(theta, i_raw, w, nthreads=16))
+    # stream-ordered launches (1 workgroup per CU, three in flight) give the same numbers as the synchronous call
+    lp_sync, g_sync = ctx.logp_dlogp(0, thetas[0])
+    for k in range(6):
+        ctx.enqueue(k, [0], thetas[k % 2][None])
+    ctx.wait()
+    lp_q, g_q = ctx.fetch_many(np.arange(6), 1)
+    np.testing.assert_allclose(lp_q[0, 0], lp_sync, rtol=1e-12)
+    np.testing.assert_allclose(lp_q[4, 0], lp_sync, rtol=1e-12)
+    np.testing.assert_allclose(g_q[2, 0], g_sync, rtol=1e-9, atol=1e-9 * np.abs(g_sync).max())
+    # the data term is a sum over individuals: two parts of the cohort add up to the whole
+    ll, gl = ctx.loglik_dlogp(0, thetas[0])
+    ctx.close()
+    parts = []
+    for lo, hi in ((0, 37000), (37000, N)):
+        part = _ctx(sc, 1, storage="f32", sub=(lo, hi))
+        part.set_discrete(0, i_raw[:, lo:hi], w[lo:hi])
+        parts.append(part.loglik_dlogp(0, thetas[0]))
+        part.close()
+    assert abs((parts[0][0] + parts[1][0]) - ll) <= 1e-11 * abs(ll)
+    np.testing.assert_allclose(parts[0][1] + parts[1][1], gl, rtol=1e-8, atol=1e-9 * np.abs(gl).max())

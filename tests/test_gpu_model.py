@@ -150,4 +150,93 @@ def test_sampler_smoke_and_cli(tmp_path, golden_dir, test_td):
     assert len(files) == 1
     if files[0].suffix == ".npz":
         z = np.load(files[0])
-        assert z["ab_n_mu"].shape == (1, 4, 26, 10) and z["it_s_sigma"].shape == (1, 4)
+        # --cores 1 -> two chains, as pm.sample(cores=1) runs max(2, cores)
+        assert z["ab_n_mu"].shape == (2, 4, 26, 10) and z["it_s_sigma"].shape == (2, 4)
+
+
+def test_both_callables_on_one_chain_slot_stay_coherent(test_td):
+    """INTEGRATION.md wires compile_logp() and logp_dlogp_function() to the same chain slot, as PyMC's compound step
+    does: NUTS re-uploads the accepted state through set_extra_values while BinaryGibbsMetropolis flips single bits
+    through the point function.  A sweep that ends on a REJECTED proposal leaves the point function's mirror on the
+    flipped state; the next sweep must not trust it once NUTS has rewritten the slot."""
+    import abdpymc_amd
+
+    coh = _oracle_cohort(test_td)
+    m = abdpymc_amd.model(test_td, splits=(14,))
+    logp_fn, fn = m.compile_logp(), m.logp_dlogp_function()
+    rng = np.random.default_rng(11)
+    pt = m.initial_point()
+    pt["i_raw"] = (rng.random((m.n_gaps, m.n_inds)) < 0.06).astype(np.int64)
+    theta = m.ravel(pt)
+
+    def ref(i_raw, w):
+        return O.logp_dlogp(theta, i_raw, w, coh, (14,))[0]
+
+    fn.set_extra_values(pt)
+    assert abs(fn(theta)[0] - ref(pt["i_raw"], pt["ab_s_waner"])) <= RTOL * abs(ref(pt["i_raw"], pt["ab_s_waner"]))
+    accepted = {k: np.array(v, copy=True) for k, v in pt.items()}
+    for sweep in range(4):
+        # a Gibbs "sweep" of a few proposals, the LAST one rejected (the caller keeps `accepted`, the device and the
+        # point function's mirror are left on the rejected proposal)
+        for k in range(3):
+            prop = {kk: np.array(v, copy=True) for kk, v in accepted.items()}
+            f = int(rng.integers(m.n_gaps * m.n_inds))
+            prop["i_raw"].ravel()[f] ^= 1
+            want = ref(prop["i_raw"], prop["ab_s_waner"])
+            assert abs(float(logp_fn(prop)) - want) <= RTOL * abs(want)
+            if k < 2:
+                accepted = prop
+        # NUTS: the accepted state goes up through the OTHER callable, then leapfrogs
+        fn.set_extra_values(accepted)
+        want = ref(accepted["i_raw"], accepted["ab_s_waner"])
+        assert abs(fn(theta)[0] - want) <= RTOL * abs(want)
+        # next sweep's first proposal differs from the stale mirror by exactly one bit more than it thinks
+        prop = {kk: np.array(v, copy=True) for kk, v in accepted.items()}
+        prop["ab_s_waner"][sweep] ^= 1
+        want = ref(prop["i_raw"], prop["ab_s_waner"])
+        assert abs(float(logp_fn(prop)) - want) <= RTOL * abs(want)
+        fn.set_extra_values(accepted)
+    # a device sweep rewrites the slot behind both callables' backs
+    m.ctx.gibbs_sweep([0], theta[None], seed=3, sweep=0)
+    i_dev, w_dev = m.ctx.get_discrete(0)
+    assert abs(float(logp_fn(accepted)) - ref(accepted["i_raw"], accepted["ab_s_waner"])) <= RTOL * abs(ref(accepted["i_raw"], accepted["ab_s_waner"]))
+    assert logp_fn.mirror.uploads >= 2 and logp_fn.mirror.flips >= 8
+    m.close()
+
+
+def test_pytensor_op_core_constrained_gradient_and_uploads(test_td):
+    """What AbdDataLogp.perform computes (PyTensor itself is not installed here): the data term as a function of the 13
+    CONSTRAINED parameters -- its gradient against central finite differences in that space, the value against the
+    oracle's joint logp minus priors -- and the discrete state is uploaded once, not per call."""
+    from abdpymc_amd.pytensor_op import _Lazy
+
+    lazy = _Lazy(test_td, (14, 20), False)
+    m = lazy.model()
+    rng = np.random.default_rng(5)
+    i_raw = (rng.random((m.n_gaps, m.n_inds)) < 0.05).astype(np.int8)
+    waner = (rng.random(m.n_inds) < 0.5).astype(np.int8)
+    params = np.array([2.1, 0.9, 0.88, -1.9, 1.8, 0.93, -2.2, -1.2, 1.7, 0.35, -0.8, 2.2, 0.4])
+    ll, g = lazy.loglik_dlogp_constrained(params, i_raw, waner)
+    for k in range(13):
+        h = 1e-6 * max(1.0, abs(params[k]))
+        up, dn = params.copy(), params.copy()
+        up[k] += h
+        dn[k] -= h
+        fd = (lazy.loglik_dlogp_constrained(up, i_raw, waner)[0] - lazy.loglik_dlogp_constrained(dn, i_raw, waner)[0]) / (2 * h)
+        assert abs(fd - g[k]) <= 2e-6 * max(abs(g[k]), 1e-3 * np.abs(g).max()), (k, fd, g[k])
+    # NUTS leapfrogs: same discrete arrays every call -> one upload in all
+    assert lazy.mirror().uploads == 1 and lazy.mirror().flips == 0 and lazy.mirror().hits == 26
+    # a Gibbs proposal: one bit differs -> one flip, no upload
+    i2 = i_raw.copy()
+    i2[3, 2] ^= 1
+    ll2, _ = lazy.loglik_dlogp_constrained(params, i2, waner)
+    assert lazy.mirror().uploads == 1 and lazy.mirror().flips == 1
+    from abdpymc_amd.pytensor_op import _theta_from_constrained
+
+    coh = _oracle_cohort(test_td)
+    theta = _theta_from_constrained(params, m.n_gaps)
+    for ir, val in ((i_raw, ll), (i2, ll2)):
+        joint = O.logp_dlogp(theta, ir, waner, coh, (14, 20))[0]
+        prior = O.prior_logp_grad(theta, m.n_gaps, m.n_gaps * m.n_inds, int(ir.sum()), m.n_inds, int(waner.sum()))[0]
+        assert abs(val - (joint - prior)) <= 1e-9 * abs(joint)
+    m.close()

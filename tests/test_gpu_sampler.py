@@ -341,6 +341,9 @@ def test_back_to_back_synchronous_calls_are_deterministic(test_td):
             ref = th
         else:
             assert np.array_equal(th, ref), r
+    # ~100 k synchronous calls were waited for by polling their completion tags: none may have needed the
+    # stream-synchronise fall-back (abd_wait_fallbacks)
+    assert m.ctx.wait_fallbacks == 0
     m.close()
 
 

@@ -121,6 +121,8 @@ struct abd_ctx {
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots + 1][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
+  unsigned int* d_work = nullptr;          // [n_slots] work queue heads of abd_gibbs_dense_kernel
+  bool gibbs_v1 = false;                   // ABD_GIBBS_V1=1: dense cohorts use the wave-per-proposal kernel too
   double* d_det = nullptr;                 // staging of abd_deterministics: mu_n, mu_s (G*N doubles each), i (G*N bytes)
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
   int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
@@ -726,6 +728,7 @@ void free_ctx(abd_ctx* c) {
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->d_work) (void)hipFree(c->d_work);
   if (c->d_det) (void)hipFree(c->d_det);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
@@ -906,6 +909,8 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   CREATE_TRY(hipMalloc(&c->d_counts, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMalloc(&c->d_work, (size_t)c->n_slots * sizeof(unsigned int)));
+  if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
   c->results.resize(kResultSlots + 1);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
@@ -1090,6 +1095,24 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
       ga.is2_s[k] = 1.0 / (tr.sig_s * tr.sig_s);
     }
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, (size_t)m * 2 * sizeof(unsigned long long), c->stream));
+    ga.work = c->d_work;
+    const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
+    const size_t lds2 = abd_g2_lds(c->G, rbytes);
+    if (c->dense && !c->gibbs_v1 && lds2 <= 160 * 1024) {
+      // lanes = proposals (abd_gibbs2.hpp): as many workgroups as stay resident (2 per CU at most: 256 registers per
+      // lane), the individuals of a chain handed out from one queue per chain
+      HIP_TRY(hipMemsetAsync(c->d_work, 0, (size_t)m * sizeof(unsigned int), c->stream));
+      const int wpc = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds2));
+      const int bx = std::max(1, std::min((c->n_cu * wpc) / m, (c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK));
+      dim3 grid2(bx, m);
+      if (c->storage == ABD_STORE_F32) {
+        if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(ABD_BLOCK), lds2, c->stream, ga);
+      } else {
+        if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(ABD_BLOCK), lds2, c->stream, ga);
+      }
+    } else {
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
     const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_GIBBS_WAVE_LDS;
     dim3 grid(blocks, m);
@@ -1103,6 +1126,7 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
         hipLaunchKernelGGL((abd_gibbs_kernel<float, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
       else
         hipLaunchKernelGGL((abd_gibbs_kernel<double, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
+    }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts.data() + (size_t)k0 * 2, c->d_counts, (size_t)m * 2 * sizeof(unsigned long long),

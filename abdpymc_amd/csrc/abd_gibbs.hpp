@@ -62,6 +62,7 @@ struct GibbsArgs {
   double is2_n[ABD_MAX_BATCH_K];   // 1 / sigma_n^2
   double is2_s[ABD_MAX_BATCH_K];
   unsigned long long* counts;      // [n_chains][2]: accepted, proposed (integer atomics: order-free)
+  unsigned int* work;              // [n_chains]: next individual of each chain (abd_gibbs_dense_kernel's work queue), zeroed per launch
 };
 
 __device__ __forceinline__ double readfirstlane_f64(double v) {

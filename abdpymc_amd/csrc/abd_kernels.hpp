@@ -612,6 +612,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
 
 #include "abd_obs.hpp"
 #include "abd_gibbs.hpp"
+#include "abd_gibbs2.hpp"
 
 // ================================================================================================
 // Small kernels

@@ -908,7 +908,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
-  CREATE_TRY(hipMalloc(&c->d_counts, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
   CREATE_TRY(hipMalloc(&c->d_work, (size_t)c->n_slots * sizeof(unsigned int)));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
   c->results.resize(kResultSlots + 1);
@@ -1096,6 +1096,18 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
     }
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, (size_t)m * 2 * sizeof(unsigned long long), c->stream));
     ga.work = c->d_work;
+    ga.refill_min = ABD_G2_REFILL_MIN;
+    ga.tail_lanes = ABD_G2_TAIL_LANES;
+    ga.tail_age = ABD_G2_TAIL_AGE;
+    if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) ga.refill_min = std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("ABD_G2_TAIL_LANES")) ga.tail_lanes = std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("ABD_G2_TAIL_AGE")) ga.tail_age = std::max(0, std::atoi(e));
+    ga.stats = nullptr;
+    static const bool want_stats = std::getenv("ABD_GIBBS_STATS") && std::atoi(std::getenv("ABD_GIBBS_STATS")) != 0;
+    if (want_stats) {
+      ga.stats = c->d_counts + (size_t)c->n_slots * 2;
+      HIP_TRY(hipMemsetAsync(ga.stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    }
     const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
     const size_t lds2 = abd_g2_lds(c->G, rbytes);
     if (c->dense && !c->gibbs_v1 && lds2 <= 160 * 1024) {
@@ -1132,6 +1144,14 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
     HIP_TRY(hipMemcpyAsync(counts.data() + (size_t)k0 * 2, c->d_counts, (size_t)m * 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ga.stats) {
+      unsigned long long st[8];
+      HIP_TRY(hipMemcpy(st, ga.stats, sizeof st, hipMemcpyDeviceToHost));
+      const double ni = (double)std::max<unsigned long long>(1, st[0]);
+      std::fprintf(stderr, "[abd gibbs stats] individuals x chains %llu; per individual: iterations %.1f, refills %.1f, walk steps %.1f "
+                   "(lanes busy %.1f of 64), tail finishes %.1f, commit scans %.1f, acceptances %.2f\n",
+                   st[0], st[1] / ni, st[2] / ni, st[3] / ni, st[3] ? (double)st[4] / (double)st[3] : 0.0, st[5] / ni, st[6] / ni, st[7] / ni);
+    }
   }
   for (int k = 0; k < n; ++k) {
     if (accepted) accepted[k] = (int64_t)counts[(size_t)k * 2];

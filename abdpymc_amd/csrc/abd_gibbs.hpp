@@ -63,6 +63,8 @@ struct GibbsArgs {
   double is2_s[ABD_MAX_BATCH_K];
   unsigned long long* counts;      // [n_chains][2]: accepted, proposed (integer atomics: order-free)
   unsigned int* work;              // [n_chains]: next individual of each chain (abd_gibbs_dense_kernel's work queue), zeroed per launch
+  unsigned long long* stats;       // nullptr, or 8 development counters of abd_gibbs_dense_kernel (ABD_GIBBS_STATS=1)
+  int32_t refill_min, tail_lanes, tail_age;  // scheduler knobs of abd_gibbs_dense_kernel (abd_gibbs2.hpp)
 };
 
 __device__ __forceinline__ double readfirstlane_f64(double v) {

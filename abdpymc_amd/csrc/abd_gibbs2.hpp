@@ -33,6 +33,8 @@
 #define ABD_G2_ACCEPT 2
 #define ABD_G2_COMPLEX 3
 #define ABD_G2_REFILL_MIN 16         // idle lanes that trigger a refill (a refill costs ~2-3 walk steps)
+#define ABD_G2_TAIL_LANES 8          // walkers left when the whole wave starts finishing them one at a time ...
+#define ABD_G2_TAIL_AGE 6            // ... those that have survived this many gaps
 #define ABD_G2_ITER_CAP (1 << 20)    // hard bound on scheduler iterations per individual (never reached: see the loop)
 
 __host__ __device__ inline size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 * 16; }
@@ -122,6 +124,21 @@ __device__ __forceinline__ uint64_t word_at(const uint64_t w[ABD_MAXT], int g) {
   return v;
 }
 
+// a wave-uniform row shifted down by g gaps (bit 0 of the result = gap g)
+__device__ __forceinline__ void shift_row_down(const uint64_t w[ABD_MAXT], int g, uint64_t out[ABD_MAXT]) {
+  const int q = g >> 6, sh = g & 63;
+#pragma unroll
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < ABD_MAXT; ++k) {
+      lo = t + q == k ? w[k] : lo;
+      hi = t + q + 1 == k ? w[k] : hi;
+    }
+    out[t] = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  }
+}
+
 // both antigens' likelihood term of one gap: -1/2 (q_n / sigma_n)^2 - 1/2 (q_s / sigma_s)^2 (terms that do not depend
 // on the discrete state are left out: they cancel in every difference)
 __device__ __forceinline__ double g2_term(double an, double xn, double yn, double c_n, double d_n, double nh_n, double as, double xs,
@@ -158,19 +175,22 @@ struct G2Par {  // wave-uniform constants of the chain
 
 // Whole-wave evaluation of one state, lanes = gaps of a round: the two responses at this lane's gap of every round
 // (carry into the round x rho^(lane+1) + this round's exposures at or before the lane, power table) and the term there.
+// The rounds start at gap g_off (0: the whole individual; otherwise I and V are the rows shifted down by g_off and
+// cvn / cvs / ci / civ the state at gap g_off - 1: the rest of one lane's walk, taken over by the whole wave).
 template <typename R>
 __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint64_t I[ABD_MAXT],
                                                const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
                                                double pwn, double pws, const YX<R>* dataN, const YX<R>* dataS,
                                                const double* tab_e2, double (&un_o)[ABD_MAXT], double (&us_o)[ABD_MAXT],
-                                               double (&term_o)[ABD_MAXT]) {
-  double cvn = 0.0, cvs = 0.0;  // responses at the end of the previous round (wave-uniform)
-  bool ci = false, civ = false;
+                                               double (&term_o)[ABD_MAXT], int g_off = 0, double cvn = 0.0, double cvs = 0.0,
+                                               bool ci = false, bool civ = false) {
+  // cvn / cvs: responses at the end of the previous round (wave-uniform)
   const uint64_t le = (2ull << lane) - 1ull;  // bits at or before this lane (lane 63: all ones)
+  const int n_rounds = (a.G - g_off + 63) >> 6;
 #pragma unroll
   for (int t = 0; t < ABD_MAXT; ++t) {
     un_o[t] = us_o[t] = term_o[t] = 0.0;
-    if (t < a.nt) {
+    if (t < n_rounds) {
       double un = pwn * cvn, us = pws * cvs;
       uint64_t m = I[t];
       while (m) {  // wave-uniform loop over this word's infections
@@ -188,7 +208,7 @@ __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p
       }
       const bool cum_i = ci || (I[t] & le) != 0;
       const bool cum_iv = civ || ((I[t] | V[t]) & le) != 0;
-      const int g = t * 64 + lane;
+      const int g = g_off + t * 64 + lane;
       const bool valid = g < a.G;
       const int gg = valid ? g : 0;
       const YX<R> on = dataN[gg], os = dataS[gg];
@@ -287,20 +307,22 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
   for (int e = tid; e < ABD_EXP2_TAB; e += ABD_BLOCK) tab_e2[e] = a.exp2_tab[e];
   __syncthreads();
 
+  // the chain's constants live in VECTOR registers: the scalar file is needed for the packed rows of the individual
+  // (five rows of four words), and a spilled scalar costs a v_readlane in the walk
   G2Par p;
-  p.perm_n = cp.perm_n;
-  p.temp_n = cp.temp_n;
-  p.rho_n = cp.rho_n;
-  p.init_n = cp.init_n;
-  p.perm_s = cp.perm_s;
-  p.rho_s = cp.rho_s;
-  p.init_s = cp.init_s;
-  p.c_n = cp.b_n * (1.4426950408889634074 * ABD_EXP2_TAB);
-  p.c_s = cp.b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
-  p.d_n = cp.d_n;
-  p.d_s = cp.d_s;
-  p.nh_n = -0.5 * ga.is2_n[c];
-  p.nh_s = -0.5 * ga.is2_s[c];
+  p.perm_n = to_vgpr(cp.perm_n);
+  p.temp_n = to_vgpr(cp.temp_n);
+  p.rho_n = to_vgpr(cp.rho_n);
+  p.init_n = to_vgpr(cp.init_n);
+  p.perm_s = to_vgpr(cp.perm_s);
+  p.rho_s = to_vgpr(cp.rho_s);
+  p.init_s = to_vgpr(cp.init_s);
+  p.c_n = to_vgpr(cp.b_n * (1.4426950408889634074 * ABD_EXP2_TAB));
+  p.c_s = to_vgpr(cp.b_s * (1.4426950408889634074 * ABD_EXP2_TAB));
+  p.d_n = to_vgpr(cp.d_n);
+  p.d_s = to_vgpr(cp.d_s);
+  p.nh_n = to_vgpr(-0.5 * ga.is2_n[c]);
+  p.nh_s = to_vgpr(-0.5 * ga.is2_s[c]);
   const double theta0 = ga.theta0[c], theta7 = ga.theta7[c];
   // rho^(lane + 1) = table entry lane + 2 (only used when a previous round exists, i.e. G > 64 >= lane + 1)
   const double pwn = tabs[min(lane + 2, G)].x, pws_w = tabs[tstride + min(lane + 2, G)].x;
@@ -309,6 +331,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
   uint64_t* rw = const_cast<uint64_t*>(cp.rw);
   int8_t* waner = const_cast<int8_t*>(cp.waner);
   unsigned long long n_acc = 0, n_prop_total = 0;
+  unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
   for (;;) {
     // ---- next individual of this chain: one queue per chain, so that the waves stay busy to the end ----
@@ -421,22 +444,27 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
     int frontier = 0, next = 0;  // positions < frontier are committed; positions < next have been handed out
     // per-lane walk state
     bool active = false;
-    int pidx = 0, g = 0;
+    int pidx = 0, g = 0, g_first = 0;
     double tn = 0.0, ts = 0.0, S = 0.0, B0 = 0.0, thr = 0.0, lu = 0.0;
     uint32_t cfn_hi = 0, cfs_hi = 0;
     uint64_t inw = 0, vw = 0, In[ABD_MAXT] = {0, 0, 0, 0};
     const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
 
+    bool dirty = false;  // a result has been written since the last commit scan
+    ++st_inds;
     for (int iter = 0; iter < ABD_G2_ITER_CAP && frontier < n_prop; ++iter) {
+      ++st_iter;
       // every iteration commits, hands out or advances at least one proposal, and an acceptance -- the only event that
       // moves `next` back -- changes the state for good: the loop ends; the cap only bounds a defect
       const double rho_j = wj ? p.rho_s : 1.0;  // abd.py:374
       // ---- 1. idle lanes pick up the next proposals ----
       const uint64_t idle_mask = __builtin_amdgcn_ballot_w64(!active);
       const int n_idle = __builtin_popcountll(idle_mask);
-      if (next < n_prop && (n_idle >= ABD_G2_REFILL_MIN || n_idle == 64)) {
+      if (next < n_prop && (n_idle >= ga.refill_min || n_idle == 64)) {
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0));
         const bool take = !active && next + rank < n_prop;
+        ++st_refill;
+        dirty = true;  // immediate results (no change / waning flip) may be among them
         if (take) {
           pidx = next + rank;
           const int d = plist[pidx];
@@ -488,7 +516,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
               inw = word_at(In, gf) >> (gf & 63);
               vw = word_at(V, gf) >> (gf & 63);
               S = 0.0;
-              g = gf;
+              g = g_first = gf;
               active = true;
             }
           }
@@ -497,6 +525,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
       }
 
       // ---- 2. one gap for every walking lane ----
+      bool finished = false;
       if (active) {
         const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)inw, 0u, 1u) & 0x3FF00000u;
         const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)vw, 0u, 1u) & 0x3FF00000u;
@@ -519,14 +548,56 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
           const double delta = B0 + S;
           result[pidx] = (!dead && (delta > 0.0 || delta > lu)) ? ABD_G2_ACCEPT : ABD_G2_REJECT;
           active = false;
+          finished = true;
         } else if ((g & 63) == 0) {
           inw = word_at(In, g);
           vw = word_at(V, g);
         }
       }
+      dirty |= __builtin_amdgcn_ballot_w64(finished) != 0;
+      // ---- 2b. the tail of an individual: every proposal has been handed out and only a few lanes still walk (a walk
+      // that is not rejected early is as long as the gaps that are left).  The whole wave finishes one of them per
+      // iteration, lanes = the remaining gaps: the bound at the last gap IS delta.
+      const uint64_t walking = __builtin_amdgcn_ballot_w64(active);
+      if (ga.stats) {
+        const uint64_t stepped = walking | __builtin_amdgcn_ballot_w64(finished);
+        st_steps += stepped != 0;
+        st_lane_steps += (unsigned long long)__builtin_popcountll(stepped);
+      }
+      // (only walks that have already survived tail_age gaps: a young one is most likely rejected within a few more)
+      const uint64_t old_walkers = __builtin_amdgcn_ballot_w64(active && g - g_first >= ga.tail_age);
+      if (next >= n_prop && old_walkers != 0 && __builtin_popcountll(walking) <= ga.tail_lanes) {
+        const int L = __builtin_ctzll(old_walkers);
+        ++st_tail;
+        const int g_l = __builtin_amdgcn_readlane(g, L);
+        uint64_t In_l[ABD_MAXT], Is[ABD_MAXT], Vs[ABD_MAXT];
+#pragma unroll
+        for (int t = 0; t < ABD_MAXT; ++t)
+          In_l[t] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(In[t] >> 32), L) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)In[t], L);
+        shift_row_down(In_l, g_l, Is);
+        shift_row_down(V, g_l, Vs);
+        const bool ci0 = __builtin_amdgcn_readlane((int)cfn_hi, L) != 0, civ0 = __builtin_amdgcn_readlane((int)cfs_hi, L) != 0;
+        double un[ABD_MAXT], us[ABD_MAXT], term[ABD_MAXT];
+        g2_eval_rounds<R>(a, p, lane, Is, Vs, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, un,
+                          us, term, g_l, readlane_f64(tn, L), readlane_f64(ts, L), ci0, civ0);
+        double tsum = 0.0;
+#pragma unroll
+        for (int t = 0; t < ABD_MAXT; ++t) tsum += term[t];
+        const double rest = wave_sum_uniform(tsum);
+        if (lane == L) {
+          const double delta = B0 + (S + rest);
+          result[pidx] = (delta > 0.0 || delta > lu) ? ABD_G2_ACCEPT : ABD_G2_REJECT;
+          active = false;
+        }
+        dirty = true;
+      }
       __builtin_amdgcn_wave_barrier();
 
       // ---- 3. commit in the sweep's order ----
+      if (!dirty) continue;
+      dirty = false;
+      ++st_commit;
       for (;;) {
         const int pos = frontier + lane;
         const int r = pos < next ? (int)result[pos] : ABD_G2_PENDING;
@@ -582,5 +653,15 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
   if (lane == 0 && (n_acc | n_prop_total)) {
     atomicAdd(ga.counts + 2 * c + 0, n_acc);
     atomicAdd(ga.counts + 2 * c + 1, n_prop_total);
+  }
+  if (lane == 0 && ga.stats) {
+    atomicAdd(ga.stats + 0, st_inds);
+    atomicAdd(ga.stats + 1, st_iter);
+    atomicAdd(ga.stats + 2, st_refill);
+    atomicAdd(ga.stats + 3, st_steps);
+    atomicAdd(ga.stats + 4, st_lane_steps);
+    atomicAdd(ga.stats + 5, st_tail);
+    atomicAdd(ga.stats + 6, st_commit);
+    atomicAdd(ga.stats + 7, n_acc);
   }
 }

@@ -44,6 +44,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kResultSlots = 1024;
 constexpr int kSyncSlot = kResultSlots;  // private rows of the synchronous calls: they never touch a caller's slot
+constexpr int kSyncSlots = 4;            // ... one per chain group the native sampler keeps in flight
 constexpr int kMinRows = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
@@ -109,7 +110,10 @@ struct abd_ctx {
     bool busy = false;  // pipe 1: work queued since the last join with pipe 0
   } pipe[4];
   int n_pipes = 3;        // streams that stream-ordered dense launches rotate over (1 = everything on the context's stream)
+  int n_streams = 4;      // pipes that exist (every chain group of the sampler has a stream of its own)
   int pipe_blocks = 0;    // dense grid of a launch that shares the chip with n_pipes - 1 others
+  int group_blocks = 0;   // dense grid of one of the sampler's chain groups in flight (set by abd_sampler_create)
+  int dbpc = 4;           // dense kernel: workgroups per CU of a launch that has the chip to itself
   int next_pipe = 0;
   hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
@@ -118,7 +122,7 @@ struct abd_ctx {
   bool xcd_remap = true;
   int fin_rows = 2;
   double prior_const = 0.0;
-  double* h_out = nullptr;     // pinned + mapped: [kResultSlots + 1][n_slots][ABD_NOUT]
+  double* h_out = nullptr;     // pinned + mapped: [kResultSlots + kSyncSlots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
   unsigned int* d_work = nullptr;          // [n_slots] work queue heads of abd_gibbs_dense_kernel
@@ -386,13 +390,17 @@ int pick_cpw(const abd_ctx* c, int n) {
 
 // grid of the dense kernel: an exact multiple of the CU count (every wave slot gets the same number of
 // gap rows), capped so a slot has at least kMinRows rows
-int dense_blocks(const abd_ctx* c, int cpw, bool shared = false, int grid_rows = 1) {
+// share: 0 = the launch has the chip to itself, 1 = it is one of n_pipes stream-ordered launches in flight,
+// 2 = it is one of the native sampler's chain groups in flight (c->group_blocks: the chip divided by their number)
+int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
   const int nsub = ABD_WAVES_PER_BLOCK / cpw;
   const int64_t rows = (int64_t)c->n_lg * c->G;
   const int64_t cap = std::max<int64_t>(1, rows / ((int64_t)kMinRows * nsub));
   // a launch with several grid rows (more than 4 chains) fills the chip with fewer, longer ranges per row
   const int64_t alone = std::max<int64_t>(c->n_cu, c->dense_blocks / std::max(1, grid_rows));
-  return (int)std::max<int64_t>(1, std::min<int64_t>({shared ? (int64_t)c->pipe_blocks : alone, cap, (int64_t)c->blocks_max}));
+  const int64_t half = std::max<int64_t>(c->n_cu, c->group_blocks / std::max(1, grid_rows));
+  const int64_t want = share == 1 ? (int64_t)c->pipe_blocks : (share == 2 ? half : alone);
+  return (int)std::max<int64_t>(1, std::min<int64_t>({want, cap, (int64_t)c->blocks_max}));
 }
 
 // queue the standalone fixed-order sum of a launch whose partials are still pending
@@ -408,7 +416,7 @@ int flush_pipe(abd_ctx* c, int pi) {
 
 // pipe 0 continues only after everything queued on pipe 1 has finished
 int join_pipes(abd_ctx* c) {
-  for (int pi = 1; pi < c->n_pipes; ++pi) {
+  for (int pi = 1; pi < c->n_streams; ++pi) {
     abd_ctx::Pipe& p = c->pipe[pi];
     if (!p.st) continue;
     if (int rc = flush_pipe(c, pi)) return rc;
@@ -429,7 +437,7 @@ int flush_pending(abd_ctx* c) {
 
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
-                  bool deferred = false) {
+                  bool deferred = false, int force_pipe = -1) {
   EvalArgs a;
   base_args(c, a);
   a.n_chains = n;
@@ -444,7 +452,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     blocks = c->ob_n + c->ob_s + c->ob_c;
     lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
   } else if (c->dense) {
-    blocks = dense_blocks(c, cpw, rotate, n / cpw);
+    blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate ? 1 : 0), n / cpw);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK, true);
   } else {
     blocks = c->blocks_x;
@@ -453,7 +461,9 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
   dim3 grid(blocks, n / cpw);
   int pi = 0;
-  if (rotate) {
+  if (force_pipe >= 0) {
+    pi = force_pipe;  // the caller keeps several synchronous groups in flight, one per pipe (abd_sampler_run_record)
+  } else if (rotate) {
     pi = c->next_pipe;
     c->next_pipe = (c->next_pipe + 1) % c->n_pipes;
   } else if (int jrc = join_pipes(c)) {
@@ -539,7 +549,7 @@ int flush_ring(abd_ctx* c) {
 
 // Wait for the rows of a synchronous call (written into mapped host memory) by polling their completion tag;
 // falls back to a stream synchronise if it does not show up quickly.
-int wait_rows(abd_ctx* c, int slot, int n, double tag) {
+int wait_rows(abd_ctx* c, int slot, int n, double tag, hipStream_t st = nullptr) {
   volatile const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
   // every row is written by its own workgroup (row, system-scope fence, tag), in no particular order: wait for
   // each tag.  Rows of an earlier group of the same call carry a smaller tag and count as landed once a later
@@ -557,7 +567,7 @@ int wait_rows(abd_ctx* c, int slot, int n, double tag) {
   // the tag did not show within ~2 M polls (tens of ms): not an error -- the stream synchronise below is always
   // correct -- but it should never happen, so it is counted (abd_wait_fallbacks) instead of passing as a slow call
   c->wait_fallbacks++;
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(st ? st : c->stream));
   return ABD_OK;
 }
 
@@ -571,8 +581,9 @@ int check_chains(abd_ctx* c, int n, const int32_t* chains) {
   return ABD_OK;
 }
 
-int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false) {
-  if (slot < 0 || slot > kSyncSlot) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
+                 int force_pipe = -1) {
+  if (slot < 0 || slot >= kSyncSlot + kSyncSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
@@ -595,14 +606,15 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   }
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
-    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred);
+    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred, force_pipe);
+    if (!rc && force_pipe >= 0) rc = flush_pipe(c, force_pipe);  // a group's fixed-order sum follows on its own stream
     if (rc) return rc;
   }
   return ABD_OK;
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true) {
-  if (slot < 0 || slot > kSyncSlot) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  if (slot < 0 || slot >= kSyncSlot + kSyncSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   const ResultSlot& r = c->results[slot];
   if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
   const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
@@ -883,8 +895,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->pipe[0].st = c->stream;
   if (const char* e = std::getenv("ABD_TWO_PIPES")) c->n_pipes = std::atoi(e) != 0 ? 2 : 1;
   if (const char* e = std::getenv("ABD_PIPES")) c->n_pipes = std::max(1, std::min(4, std::atoi(e)));
-  if (!c->dense) c->n_pipes = 1;
-  for (int pi = 1; pi < c->n_pipes; ++pi) {
+  if (!c->dense) c->n_pipes = 1;  // only the dense kernel has a grid for sharing the chip; the others just overlap
+  c->n_streams = 4;
+  for (int pi = 1; pi < c->n_streams; ++pi) {
     CREATE_TRY(hipStreamCreateWithFlags(&c->pipe[pi].st, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->join_ev[pi], hipEventDisableTiming));
   }
@@ -893,6 +906,8 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->pipe_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, dbpc / c->n_pipes));  // measured best: 3 pipes x 1 workgroup per CU
   if (const char* e = std::getenv("ABD_PIPE_BLOCKS_PER_CU")) c->pipe_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
   if (const char* e = std::getenv("ABD_PIPE_BLOCKS")) c->pipe_blocks = std::max(1, std::min(std::atoi(e), c->blocks_max));
+  c->dbpc = dbpc;
+  c->group_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, dbpc / 2));
   for (int pi = 0; pi < 4; ++pi)
     if (c->pipe[pi].st)
       for (int b = 0; b < 2; ++b)
@@ -900,7 +915,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_XCD_REMAP")) c->xcd_remap = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
-  const size_t out_bytes = (size_t)(kResultSlots + 1) * c->n_slots * ABD_NOUT * sizeof(double);
+  const size_t out_bytes = (size_t)(kResultSlots + kSyncSlots) * c->n_slots * ABD_NOUT * sizeof(double);
   // COHERENT (fine-grained) on purpose: synchronous calls poll a completion tag in this memory while the stream
   // is still running.  With hipHostMallocMapped alone the allocation is non-coherent: the GPU caches it and the
   // two 64-byte halves of a result row could reach the host in either order (tag visible, data stale).
@@ -911,7 +926,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
   CREATE_TRY(hipMalloc(&c->d_work, (size_t)c->n_slots * sizeof(unsigned int)));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
-  c->results.resize(kResultSlots + 1);
+  c->results.resize(kResultSlots + kSyncSlots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -1285,6 +1300,17 @@ struct abd_sampler {
   // scratch of one lock-step round
   std::vector<int32_t> ids, who;
   std::vector<double> th, lp, gr;
+  // NUTS runs the chains as two groups, each with its own launch in flight (pipe g, private result rows g): while
+  // the host feeds one group's results to its trees and builds the next leapfrog points, the other group's
+  // evaluation is running
+  struct Group {
+    int lo = 0, hi = 0, m = 0;
+    bool pending = false;
+    double tag = 0.0;
+    std::vector<int32_t> ids, who;
+    std::vector<double> th, lp, gr;
+  } grp[4];
+  int n_groups = 1;
 };
 
 namespace {
@@ -1338,6 +1364,27 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   s->th.resize((size_t)n * ABD_N_THETA);
   s->lp.resize((size_t)n);
   s->gr.resize((size_t)n * ABD_N_THETA);
+  // up to four groups of (almost) equal size, contiguous chain ranges.  Measured (tools/probe_nuts_rate.py): two groups
+  // gain 0-10 % over one, four lose again -- an iteration lasts as long as its longest tree times the latency of one
+  // evaluation call, which more launches in flight do not shorten
+  s->n_groups = std::min(2, n);
+  if (const char* e = std::getenv("ABD_SAMPLER_GROUPS")) s->n_groups = std::max(1, std::min({4, n, std::atoi(e)}));
+  for (int g = 0, lo = 0; g < 4; ++g) {
+    abd_sampler::Group& gr = s->grp[g];
+    const int size = g < s->n_groups ? n / s->n_groups + (g < n % s->n_groups ? 1 : 0) : 0;
+    gr.lo = lo;
+    gr.hi = lo + size;
+    lo += size;
+    const size_t cap = (size_t)std::max(1, size);
+    gr.ids.resize(cap);
+    gr.who.resize(cap);
+    gr.th.resize(cap * ABD_N_THETA);
+    gr.lp.resize(cap);
+    gr.gr.resize(cap * ABD_N_THETA);
+  }
+  // a group's launch shares the chip with the other groups' launches
+  c->group_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, c->dbpc / s->n_groups));
+  if (const char* e = std::getenv("ABD_GROUP_BLOCKS_PER_CU")) c->group_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
   rc = abd_logp_dlogp_batch(c, n, chains, theta0, s->lp.data(), s->gr.data());
   if (rc) {
     delete s;
@@ -1466,23 +1513,70 @@ int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double
   int64_t staged = 0, flushed_to = recording ? rec->first : 0;
   std::vector<int64_t> acc((size_t)n, 0), prop((size_t)n, 0);
   for (int64_t k = 0; k < n_iter; ++k) {
-    // ---- NUTS: all chains advance one leapfrog per launch until every tree has stopped ----
+    // ---- NUTS: the chains of a group advance one leapfrog per launch until every tree has stopped; the two groups'
+    // launches overlap (a chain's trajectory does not depend on the other group: own random stream, own rows) ----
     for (auto& a : s->ch) a.begin();
-    for (;;) {
-      int m = 0;
-      for (int j = 0; j < n; ++j) {
+    auto launch = [&](int g) -> int {
+      abd_sampler::Group& gr = s->grp[g];
+      gr.m = 0;
+      gr.pending = false;
+      for (int j = gr.lo; j < gr.hi; ++j) {
         abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
         if (!nu.active) continue;
-        s->ids[(size_t)m] = s->chains[(size_t)j];
-        s->who[(size_t)m] = j;
-        std::memcpy(s->th.data() + (size_t)m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
-        ++m;
+        gr.ids[(size_t)gr.m] = s->chains[(size_t)j];
+        gr.who[(size_t)gr.m] = j;
+        std::memcpy(gr.th.data() + (size_t)gr.m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
+        ++gr.m;
       }
-      if (m == 0) break;
-      int rc = abd_logp_dlogp_batch(c, m, s->ids.data(), s->th.data(), s->lp.data(), s->gr.data());
+      if (gr.m == 0) return ABD_OK;
+      int rc = enqueue_slot(c, kSyncSlot + g, gr.m, gr.ids.data(), gr.th.data(), true, false, g);
       if (rc) return rc;
-      for (int j = 0; j < m; ++j)
-        s->ch[(size_t)s->who[(size_t)j]].nuts.feed(s->lp[(size_t)j], s->gr.data() + (size_t)j * ABD_N_THETA);
+      gr.tag = c->seq;
+      gr.pending = true;
+      return ABD_OK;
+    };
+    auto ready = [&](int g) -> bool {  // have all result rows of the group's launch landed? (never blocks)
+      const abd_sampler::Group& gr = s->grp[g];
+      volatile const double* rows = c->h_out + (size_t)(kSyncSlot + g) * c->n_slots * ABD_NOUT;
+      const int first = ((gr.m - 1) / ABD_MAX_BATCH) * ABD_MAX_BATCH;
+      for (int k = gr.m - 1; k >= first; --k)
+        if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] != gr.tag) return false;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return true;
+    };
+    auto complete = [&](int g) -> int {
+      abd_sampler::Group& gr = s->grp[g];
+      if (int frc = fetch_slot(c, kSyncSlot + g, gr.lp.data(), gr.gr.data())) return frc;
+      for (int j = 0; j < gr.m; ++j)
+        s->ch[(size_t)gr.who[(size_t)j]].nuts.feed(gr.lp[(size_t)j], gr.gr.data() + (size_t)j * ABD_N_THETA);
+      return ABD_OK;
+    };
+    HIP_TRY(hipSetDevice(c->device));
+    if (int frc = flush_ring(c)) return frc;
+    for (int g = 0; g < s->n_groups; ++g)
+      if (int rc = launch(g)) return rc;
+    for (long spins = 0;;) {
+      bool any = false, progressed = false;
+      for (int g = 0; g < s->n_groups; ++g) {
+        if (!s->grp[g].pending) continue;
+        any = true;
+        if (!ready(g)) continue;
+        if (int rc = complete(g)) return rc;
+        if (int rc = launch(g)) return rc;
+        progressed = true;
+      }
+      if (!any) break;
+      if (progressed) {
+        spins = 0;
+      } else if (++spins > 4000000) {
+        // no tag for tens of ms: fall back to synchronising the groups' streams (counted, see abd_wait_fallbacks)
+        c->wait_fallbacks++;
+        for (int g = 0; g < s->n_groups; ++g)
+          if (s->grp[g].pending) HIP_TRY(hipStreamSynchronize(c->pipe[g].st));
+        spins = 0;
+      } else {
+        __builtin_ia32_pause();
+      }
     }
     const bool draw = s->it >= s->o.tune;
     for (auto& a : s->ch) a.end_transition();

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""logp+grad evaluations per second AS THE NATIVE SAMPLER SEES THEM (NUTS only, no sweep): leapfrogs of all chains
+per wall second inside abd_sampler_run.  usage: probe_nuts_rate.py [c3|c2|default] [chains] [iterations]
+ABD_SAMPLER_GROUPS=1 runs all chains as one lock-step group (one launch in flight), the default is two groups."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from abdpymc_amd import synthetic  # noqa: E402
+from abdpymc_amd._native import Context  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+if cfg == "default":
+    from abdpymc_amd.model import model
+    from tests.test_data_loader import default_cohort
+
+    td = default_cohort(os.path.join(ROOT, "tests", "golden"))
+    m = model(td, splits=(14, 20), n_chains=C)
+    ctx, G, N = m.ctx, td.n_gaps, td.n_inds
+    pt = m.initial_point()
+    states = [(pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))] * C
+    th0 = np.stack([m.ravel(pt) + 0.1 * np.random.default_rng(c).uniform(-1, 1, 17) for c in range(C)])
+else:
+    N, G = {"c2": (1000, 60), "c3": (10000, 200)}[cfg]
+    sc = synthetic.make_cohort(N, G)
+    ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C)
+    states = [synthetic.make_chain_state(N, G, c) for c in range(C)]
+    th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+for c in range(C):
+    ctx.set_discrete(c, *states[c])
+smp = ctx.sampler(np.arange(C), th0, tune=10 ** 6, seed=3, gibbs=False)
+smp.run(15)  # step size settles
+t0 = time.perf_counter()
+_, st = smp.run(iters)
+dt = time.perf_counter() - t0
+evals = float(st["n_steps"].sum())
+print(f"{cfg} chains={C} groups={os.environ.get('ABD_SAMPLER_GROUPS', '2')}: {evals / dt:,.0f} evals/s as seen by NUTS "
+      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms per lock-step iteration)")
+smp.close()

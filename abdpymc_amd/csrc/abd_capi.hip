@@ -1124,20 +1124,20 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
       HIP_TRY(hipMemsetAsync(ga.stats, 0, 8 * sizeof(unsigned long long), c->stream));
     }
     const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
-    const size_t lds2 = abd_g2_lds(c->G, rbytes);
-    if (c->dense && !c->gibbs_v1 && lds2 <= 160 * 1024) {
-      // lanes = proposals (abd_gibbs2.hpp): as many workgroups as stay resident (2 per CU at most: 256 registers per
-      // lane), the individuals of a chain handed out from one queue per chain
+    const int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
+    if (c->dense && !c->gibbs_v1 && nw2 >= 4) {
+      // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
+      // per chain
+      const size_t lds2 = abd_g2_lds(c->G, rbytes, nw2);
       HIP_TRY(hipMemsetAsync(c->d_work, 0, (size_t)m * sizeof(unsigned int), c->stream));
-      const int wpc = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds2));
-      const int bx = std::max(1, std::min((c->n_cu * wpc) / m, (c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK));
+      const int bx = std::max(1, std::min(c->n_cu / m, (c->N + nw2 - 1) / nw2));
       dim3 grid2(bx, m);
       if (c->storage == ABD_STORE_F32) {
         if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(ABD_BLOCK), lds2, c->stream, ga);
+        hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(64 * nw2), lds2, c->stream, ga);
       } else {
         if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(ABD_BLOCK), lds2, c->stream, ga);
+        hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(64 * nw2), lds2, c->stream, ga);
       }
     } else {
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));

@@ -37,20 +37,29 @@
 #define ABD_G2_TAIL_AGE 6            // ... those that have survived this many gaps
 #define ABD_G2_ITER_CAP (1 << 20)    // hard bound on scheduler iterations per individual (never reached: see the loop)
 
+#define ABD_G2_MAX_WAVES 12  // waves of a workgroup (= of a CU: one workgroup per CU, three waves per SIMD, <= 168 registers)
 __host__ __device__ inline size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 * 16; }
-// per-wave LDS bytes
+// per-wave LDS bytes (9.6 KB at G = 200, fp64: LDS, not registers, decides how many waves a CU holds)
 __host__ __device__ inline size_t abd_g2_wave_lds(int G, int rbytes) {
   size_t b = abd_g2_pad16((size_t)G * 2 * rbytes) * 2;  // {od, log_dilution} per gap, N then S
-  b += (size_t)G * 16;                                   // {U_n, U_s} at the current state
   b += abd_g2_pad16((size_t)(G + 1) * 8);                // suf[g] = -(sum of the current terms of gaps >= g); suf[G] = 0
-  b += abd_g2_pad16((size_t)(G + 1) * 8);                // log u by dim
+  b += abd_g2_pad16((size_t)(G + 1) * 4);                // the acceptance draw's Philox word by dim
   b += abd_g2_pad16((size_t)(G + 1) * 2);                // proposal list: dim by position in the sweep
   b += abd_g2_pad16((size_t)(G + 1));                    // result by position
   return b;
 }
-// per-workgroup LDS bytes: [2][G+1] power tables + [G+1] ones + 2^(j/1024) table + the waves' areas
-__host__ __device__ inline size_t abd_g2_lds(int G, int rbytes) {
-  return (size_t)3 * (G + 1) * sizeof(double2_t) + (size_t)ABD_EXP2_TAB * sizeof(double) + ABD_WAVES_PER_BLOCK * abd_g2_wave_lds(G, rbytes);
+// LDS of the tables every wave of the workgroup shares: [2][G+1] power tables + [G+1] ones + 2^(j/1024)
+__host__ __device__ inline size_t abd_g2_shared_lds(int G) {
+  return (size_t)3 * (G + 1) * sizeof(double2_t) + (size_t)ABD_EXP2_TAB * sizeof(double);
+}
+// waves per workgroup that fit the CU's 160 KB (0: not even one)
+__host__ __device__ inline int abd_g2_waves(int G, int rbytes) {
+  const size_t avail = (size_t)160 * 1024 - abd_g2_shared_lds(G);
+  const size_t w = avail / abd_g2_wave_lds(G, rbytes);
+  return (int)(w > ABD_G2_MAX_WAVES ? ABD_G2_MAX_WAVES : w);
+}
+__host__ __device__ inline size_t abd_g2_lds(int G, int rbytes, int n_waves) {
+  return abd_g2_shared_lds(G) + (size_t)n_waves * abd_g2_wave_lds(G, rbytes);
 }
 
 // i0 of constrain_infections before the three-gap pass (abd.py:643-647 one chunk; abd.py:818 + 771 per chunk otherwise).
@@ -280,7 +289,7 @@ __device__ __forceinline__ void bitonic_sort_256(uint32_t (&k)[4], int lane) {
 }
 
 template <typename R>
-__global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
+__global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
   const int G = a.G, N = a.N, nt = a.nt;
@@ -290,21 +299,21 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
   double* tab_e2 = reinterpret_cast<double*>(tab_ones + tstride);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_threads = (int)blockDim.x;  // 64 x the waves that fit the CU's LDS (abd_g2_waves)
   unsigned char* wb = reinterpret_cast<unsigned char*>(tab_e2 + ABD_EXP2_TAB) + (size_t)wave * abd_g2_wave_lds(G, (int)sizeof(R));
   YX<R>* dataN = reinterpret_cast<YX<R>*>(wb);
   YX<R>* dataS = reinterpret_cast<YX<R>*>(wb + abd_g2_pad16((size_t)G * sizeof(YX<R>)));
-  double2_t* tcur = reinterpret_cast<double2_t*>(wb + 2 * abd_g2_pad16((size_t)G * sizeof(YX<R>)));
-  double* suf = reinterpret_cast<double*>(tcur + G);
-  double* logu = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(suf) + abd_g2_pad16((size_t)(G + 1) * 8));
-  uint16_t* plist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(logu) + abd_g2_pad16((size_t)(G + 1) * 8));
+  double* suf = reinterpret_cast<double*>(wb + 2 * abd_g2_pad16((size_t)G * sizeof(YX<R>)));
+  uint32_t* accw = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(suf) + abd_g2_pad16((size_t)(G + 1) * 8));
+  uint16_t* plist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(accw) + abd_g2_pad16((size_t)(G + 1) * 4));
   unsigned char* result = reinterpret_cast<unsigned char*>(plist) + abd_g2_pad16((size_t)(G + 1) * 2);
 
   const int c = blockIdx.y;  // one chain per block row
   const ChainPar& cp = a.ch[c];
-  fill_pow_table(tabs, cp.rho_n, tstride, tid, ABD_BLOCK);
-  fill_pow_table(tabs + tstride, cp.rho_s, tstride, tid, ABD_BLOCK);
-  fill_ones_table(tab_ones, tstride, tid, ABD_BLOCK);
-  for (int e = tid; e < ABD_EXP2_TAB; e += ABD_BLOCK) tab_e2[e] = a.exp2_tab[e];
+  fill_pow_table(tabs, cp.rho_n, tstride, tid, n_threads);
+  fill_pow_table(tabs + tstride, cp.rho_s, tstride, tid, n_threads);
+  fill_ones_table(tab_ones, tstride, tid, n_threads);
+  for (int e = tid; e < ABD_EXP2_TAB; e += n_threads) tab_e2[e] = a.exp2_tab[e];
   __syncthreads();
 
   // the chain's constants live in VECTOR registers: the scalar file is needed for the packed rows of the individual
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
         const Philox4 rr = philox4x32_10((uint32_t)d, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
         if (rr.w[1] < ABD_TRANSIT_P_U32) {
           key[r] = (rr.w[0] & ~0x1FFu) | (uint32_t)d;
-          logu[d] = log_uniform_u32(rr.w[2], tab_e2);
+          accw[d] = rr.w[2];
         }
       }
       n_prop += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[r] != 0xFFFFFFFFu));
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
     if (w_proposed) {
       if (lane == 0) {
         plist[w_rank] = (uint16_t)G;
-        logu[G] = log_uniform_u32(rwz.w[2], tab_e2);
+        accw[G] = rwz.w[2];
       }
       n_prop += 1;
     }
@@ -423,13 +432,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
             x += lane + off < 64 ? y : 0.0;
           }
           x += carry;
-          if (g < G) {
-            suf[g] = x;
-            double2_t tt;
-            tt.x = un[t];
-            tt.y = us[t];
-            tcur[g] = tt;
-          }
+          if (g < G) suf[g] = x;
           carry = readlane_f64(x, 0);
         }
       }
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
         if (take) {
           pidx = next + rank;
           const int d = plist[pidx];
-          lu = logu[d];
+          lu = log_uniform_u32(accw[d], tab_e2);  // log of the acceptance uniform, ~18 instructions
           if (d == G) {
             result[pidx] = ABD_G2_COMPLEX;  // ab_s_waner: evaluated by the whole wave at the frontier
           } else {
@@ -508,9 +511,29 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
             } else {
               B0 = delta0 + suf[gf];  // everything the current state holds from gf on is given up
               thr = lu - 1e-9 * (fabs(B0) + 1.0);
-              const double2_t t0 = tcur[max(gf - 1, 0)];
-              tn = gf > 0 ? t0.x : 0.0;
-              ts = gf > 0 ? t0.y : 0.0;
+              // the two responses at gap gf - 1 of the CURRENT state (the states agree below gf): the dense design
+              // (abd.py:258-274) summed over the current exposures, wave-uniform loops, per-lane table index
+              {
+                const double2_t* tsb = wj ? tabs + tstride : tab_ones;
+                tn = ts = 0.0;
+#pragma unroll
+                for (int t = 0; t < ABD_MAXT; ++t) {
+                  uint64_t m = I[t];
+                  while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int idx = min(max(gf - (t * 64 + b), 0), G);  // 0 = "at or after gf": contributes nothing
+                    tn += tabs[idx].x;
+                    ts += tsb[idx].x;
+                  }
+                  m = V[t];
+                  while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    ts += tsb[min(max(gf - (t * 64 + b), 0), G)].x;
+                  }
+                }
+              }
               cfn_hi = firstI < gf ? 0x3FF00000u : 0u;
               cfs_hi = min(firstI, firstV) < gf ? 0x3FF00000u : 0u;
               inw = word_at(In, gf) >> (gf & 63);
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 2) void abd_gibbs_dense_kernel(const Gib
 #pragma unroll
           for (int t = 0; t < ABD_MAXT; ++t) tsum += term[t];
           const double delta = (wn ? theta7 : -theta7) + (wave_sum_uniform(tsum) - total_cur);  // Bernoulli(waner | p_waner) abd.py:373
-          const double log_u = readfirstlane_f64(logu[G]);
+          const double log_u = readfirstlane_f64(log_uniform_u32(accw[G], tab_e2));
           accepted = delta > 0.0 || delta > log_u;
           if (accepted) wj = wn;
         } else if (accepted) {

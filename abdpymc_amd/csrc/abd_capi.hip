@@ -44,7 +44,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kResultSlots = 1024;
 constexpr int kSyncSlot = kResultSlots;  // private rows of the synchronous calls: they never touch a caller's slot
-constexpr int kSyncSlots = 4;            // ... one per chain group the native sampler keeps in flight
+constexpr int kMaxPipes = 8;             // HIP streams of a context
 constexpr int kMinRows = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
@@ -108,24 +108,27 @@ struct abd_ctx {
     double* out = nullptr;
     double tag = 0.0;
     bool busy = false;  // pipe 1: work queued since the last join with pipe 0
-  } pipe[4];
+  } pipe[kMaxPipes];
   int n_pipes = 3;        // streams that stream-ordered dense launches rotate over (1 = everything on the context's stream)
-  int n_streams = 4;      // pipes that exist (every chain group of the sampler has a stream of its own)
+  int n_streams = kMaxPipes;  // pipes that exist (the native sampler gives every chain a stream: chain k -> pipe k mod 8)
+  int n_sync_slots = 4;   // private result rows of synchronous calls (slot kSyncSlot) and of the sampler's chains in flight
   int pipe_blocks = 0;    // dense grid of a launch that shares the chip with n_pipes - 1 others
   int group_blocks = 0;   // dense grid of one of the sampler's chain groups in flight (set by abd_sampler_create)
   int dbpc = 4;           // dense kernel: workgroups per CU of a launch that has the chip to itself
   int next_pipe = 0;
-  hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t join_ev[kMaxPipes] = {};
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;
   double prior_const = 0.0;
-  double* h_out = nullptr;     // pinned + mapped: [kResultSlots + kSyncSlots][n_slots][ABD_NOUT]
+  double* h_out = nullptr;     // pinned + mapped: [kResultSlots + n_sync_slots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
-  unsigned int* d_work = nullptr;          // [n_slots] work queue heads of abd_gibbs_dense_kernel
+  unsigned int* d_work = nullptr;          // [2][n_slots] work queue heads of abd_gibbs_dense_kernel (second half: per-chain sweeps of the sampler)
+  unsigned long long* d_counts_chain = nullptr;  // [n_slots][2] counts of the sampler's per-chain sweeps ...
+  unsigned long long* h_counts_chain = nullptr;  // ... and their pinned host copy
   bool gibbs_v1 = false;                   // ABD_GIBBS_V1=1: dense cohorts use the wave-per-proposal kernel too
   double* d_det = nullptr;                 // staging of abd_deterministics: mu_n, mu_s (G*N doubles each), i (G*N bytes)
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
@@ -583,7 +586,7 @@ int check_chains(abd_ctx* c, int n, const int32_t* chains) {
 
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
                  int force_pipe = -1) {
-  if (slot < 0 || slot >= kSyncSlot + kSyncSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  if (slot < 0 || slot >= kSyncSlot + c->n_sync_slots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
@@ -614,7 +617,7 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true) {
-  if (slot < 0 || slot >= kSyncSlot + kSyncSlots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
+  if (slot < 0 || slot >= kSyncSlot + c->n_sync_slots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   const ResultSlot& r = c->results[slot];
   if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
   const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
@@ -728,12 +731,12 @@ void free_ctx(abd_ctx* c) {
     if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
   }
-  for (int pi = 1; pi < 4; ++pi)
+  for (int pi = 1; pi < kMaxPipes; ++pi)
     if (c->pipe[pi].st) (void)hipStreamSynchronize(c->pipe[pi].st);
-  for (int pi = 0; pi < 4; ++pi)
+  for (int pi = 0; pi < kMaxPipes; ++pi)
     for (int b = 0; b < 2; ++b)
       if (c->pipe[pi].partials[b]) (void)hipFree(c->pipe[pi].partials[b]);
-  for (int pi = 1; pi < 4; ++pi) {
+  for (int pi = 1; pi < kMaxPipes; ++pi) {
     if (c->join_ev[pi]) (void)hipEventDestroy(c->join_ev[pi]);
     if (c->pipe[pi].st) (void)hipStreamDestroy(c->pipe[pi].st);
   }
@@ -741,6 +744,8 @@ void free_ctx(abd_ctx* c) {
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_work) (void)hipFree(c->d_work);
+  if (c->d_counts_chain) (void)hipFree(c->d_counts_chain);
+  if (c->h_counts_chain) (void)hipHostFree(c->h_counts_chain);
   if (c->d_det) (void)hipFree(c->d_det);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
@@ -896,7 +901,8 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_TWO_PIPES")) c->n_pipes = std::atoi(e) != 0 ? 2 : 1;
   if (const char* e = std::getenv("ABD_PIPES")) c->n_pipes = std::max(1, std::min(4, std::atoi(e)));
   if (!c->dense) c->n_pipes = 1;  // only the dense kernel has a grid for sharing the chip; the others just overlap
-  c->n_streams = 4;
+  c->n_streams = kMaxPipes;
+  c->n_sync_slots = std::max(4, c->n_slots);
   for (int pi = 1; pi < c->n_streams; ++pi) {
     CREATE_TRY(hipStreamCreateWithFlags(&c->pipe[pi].st, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->join_ev[pi], hipEventDisableTiming));
@@ -908,14 +914,14 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_PIPE_BLOCKS")) c->pipe_blocks = std::max(1, std::min(std::atoi(e), c->blocks_max));
   c->dbpc = dbpc;
   c->group_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, dbpc / 2));
-  for (int pi = 0; pi < 4; ++pi)
+  for (int pi = 0; pi < kMaxPipes; ++pi)
     if (c->pipe[pi].st)
       for (int b = 0; b < 2; ++b)
         CREATE_TRY(hipMalloc(&c->pipe[pi].partials[b], (size_t)c->n_slots * c->blocks_max * ABD_NOUT * sizeof(double)));
   if (const char* e = std::getenv("ABD_FUSE_FINALIZE")) c->fuse_finalize = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_XCD_REMAP")) c->xcd_remap = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_FIN_ROWS")) c->fin_rows = std::max(0, std::atoi(e));
-  const size_t out_bytes = (size_t)(kResultSlots + kSyncSlots) * c->n_slots * ABD_NOUT * sizeof(double);
+  const size_t out_bytes = (size_t)(kResultSlots + c->n_sync_slots) * c->n_slots * ABD_NOUT * sizeof(double);
   // COHERENT (fine-grained) on purpose: synchronous calls poll a completion tag in this memory while the stream
   // is still running.  With hipHostMallocMapped alone the allocation is non-coherent: the GPU caches it and the
   // two 64-byte halves of a result row could reach the host in either order (tag visible, data stale).
@@ -924,9 +930,11 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
-  CREATE_TRY(hipMalloc(&c->d_work, (size_t)c->n_slots * sizeof(unsigned int)));
+  CREATE_TRY(hipMalloc(&c->d_work, (size_t)2 * c->n_slots * sizeof(unsigned int)));
+  CREATE_TRY(hipMalloc(&c->d_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
-  c->results.resize(kResultSlots + kSyncSlots);
+  c->results.resize((size_t)kResultSlots + c->n_sync_slots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -1078,6 +1086,75 @@ int abd_deterministics(abd_ctx* c, int32_t chain, const double* theta, int8_t* i
   return ABD_OK;
 }
 
+// Queue one sweep launch for m <= ABD_MAX_BATCH chains on stream st (nothing is waited for): counts of chain k of the
+// launch go to counts_dev[2 k .. 2 k + 1] (zeroed first), the dense kernel's work queues are work_dev[0 .. m).
+static int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
+                         uint32_t stream_offset, hipStream_t st, unsigned long long* counts_dev, unsigned int* work_dev,
+                         unsigned long long* stats_dev) {
+  GibbsArgs ga;
+  base_args(c, ga.e);
+  ga.e.n_chains = m;
+  ga.seed_lo = (uint32_t)seed;
+  ga.seed_hi = (uint32_t)(seed >> 32);
+  ga.sweep = sweep;
+  ga.ind_offset = c->ind_offset;
+  ga.counts = counts_dev;
+  for (int k = 0; k < m; ++k) {
+    const double* t = theta + (size_t)k * ABD_N_THETA;
+    ga.e.ch[k] = chain_par(c, chains[k], t);
+    const Transformed tr = transform(t);
+    ga.stream[k] = (uint32_t)chains[k] + stream_offset;
+    ga.theta0[k] = t[0];
+    ga.theta7[k] = t[7];
+    ga.is2_n[k] = 1.0 / (tr.sig_n * tr.sig_n);
+    ga.is2_s[k] = 1.0 / (tr.sig_s * tr.sig_s);
+  }
+  HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)m * 2 * sizeof(unsigned long long), st));
+  ga.work = work_dev;
+  ga.refill_min = ABD_G2_REFILL_MIN;
+  ga.tail_lanes = ABD_G2_TAIL_LANES;
+  ga.tail_age = ABD_G2_TAIL_AGE;
+  if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) ga.refill_min = std::max(1, std::min(64, std::atoi(e)));
+  if (const char* e = std::getenv("ABD_G2_TAIL_LANES")) ga.tail_lanes = std::max(0, std::min(64, std::atoi(e)));
+  if (const char* e = std::getenv("ABD_G2_TAIL_AGE")) ga.tail_age = std::max(0, std::atoi(e));
+  ga.stats = stats_dev;
+  if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, 8 * sizeof(unsigned long long), st));
+  const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
+  const int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
+  if (c->dense && !c->gibbs_v1 && nw2 >= 4) {
+    // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
+    // per chain
+    const size_t lds2 = abd_g2_lds(c->G, rbytes, nw2);
+    HIP_TRY(hipMemsetAsync(work_dev, 0, (size_t)m * sizeof(unsigned int), st));
+    const int bx = std::max(1, std::min(c->n_cu / m, (c->N + nw2 - 1) / nw2));
+    dim3 grid2(bx, m);
+    if (c->storage == ABD_STORE_F32) {
+      if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(64 * nw2), lds2, st, ga);
+    } else {
+      if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(64 * nw2), lds2, st, ga);
+    }
+  } else {
+    const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
+    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_GIBBS_WAVE_LDS;
+    dim3 grid(blocks, m);
+    if (c->dense) {
+      if (c->storage == ABD_STORE_F32)
+        hipLaunchKernelGGL((abd_gibbs_kernel<float, true>), grid, dim3(ABD_BLOCK), lds, st, ga);
+      else
+        hipLaunchKernelGGL((abd_gibbs_kernel<double, true>), grid, dim3(ABD_BLOCK), lds, st, ga);
+    } else {
+      if (c->storage == ABD_STORE_F32)
+        hipLaunchKernelGGL((abd_gibbs_kernel<float, false>), grid, dim3(ABD_BLOCK), lds, st, ga);
+      else
+        hipLaunchKernelGGL((abd_gibbs_kernel<double, false>), grid, dim3(ABD_BLOCK), lds, st, ga);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return ABD_OK;
+}
+
 static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
                             uint32_t stream_offset, int64_t* accepted, int64_t* proposed) {
   if (!c || !chains || !theta) return fail(ABD_ERR_ARG, "NULL argument");
@@ -1089,79 +1166,19 @@ static int gibbs_sweep_impl(abd_ctx* c, int32_t n, const int32_t* chains, const 
   HIP_TRY(hipSetDevice(c->device));
   if (int frc = flush_ring(c)) return frc;
   std::vector<unsigned long long> counts((size_t)n * 2, 0);
+  static const bool want_stats = std::getenv("ABD_GIBBS_STATS") && std::atoi(std::getenv("ABD_GIBBS_STATS")) != 0;
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
-    GibbsArgs ga;
-    base_args(c, ga.e);
-    ga.e.n_chains = m;
-    ga.seed_lo = (uint32_t)seed;
-    ga.seed_hi = (uint32_t)(seed >> 32);
-    ga.sweep = sweep;
-    ga.ind_offset = c->ind_offset;
-    ga.counts = c->d_counts;
-    for (int k = 0; k < m; ++k) {
-      const double* t = theta + (size_t)(k0 + k) * ABD_N_THETA;
-      ga.e.ch[k] = chain_par(c, chains[k0 + k], t);
-      const Transformed tr = transform(t);
-      ga.stream[k] = (uint32_t)chains[k0 + k] + stream_offset;
-      ga.theta0[k] = t[0];
-      ga.theta7[k] = t[7];
-      ga.is2_n[k] = 1.0 / (tr.sig_n * tr.sig_n);
-      ga.is2_s[k] = 1.0 / (tr.sig_s * tr.sig_s);
-    }
-    HIP_TRY(hipMemsetAsync(c->d_counts, 0, (size_t)m * 2 * sizeof(unsigned long long), c->stream));
-    ga.work = c->d_work;
-    ga.refill_min = ABD_G2_REFILL_MIN;
-    ga.tail_lanes = ABD_G2_TAIL_LANES;
-    ga.tail_age = ABD_G2_TAIL_AGE;
-    if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) ga.refill_min = std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("ABD_G2_TAIL_LANES")) ga.tail_lanes = std::max(0, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("ABD_G2_TAIL_AGE")) ga.tail_age = std::max(0, std::atoi(e));
-    ga.stats = nullptr;
-    static const bool want_stats = std::getenv("ABD_GIBBS_STATS") && std::atoi(std::getenv("ABD_GIBBS_STATS")) != 0;
-    if (want_stats) {
-      ga.stats = c->d_counts + (size_t)c->n_slots * 2;
-      HIP_TRY(hipMemsetAsync(ga.stats, 0, 8 * sizeof(unsigned long long), c->stream));
-    }
-    const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
-    const int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
-    if (c->dense && !c->gibbs_v1 && nw2 >= 4) {
-      // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
-      // per chain
-      const size_t lds2 = abd_g2_lds(c->G, rbytes, nw2);
-      HIP_TRY(hipMemsetAsync(c->d_work, 0, (size_t)m * sizeof(unsigned int), c->stream));
-      const int bx = std::max(1, std::min(c->n_cu / m, (c->N + nw2 - 1) / nw2));
-      dim3 grid2(bx, m);
-      if (c->storage == ABD_STORE_F32) {
-        if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(64 * nw2), lds2, c->stream, ga);
-      } else {
-        if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(64 * nw2), lds2, c->stream, ga);
-      }
-    } else {
-    const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_GIBBS_WAVE_LDS;
-    dim3 grid(blocks, m);
-    if (c->dense) {
-      if (c->storage == ABD_STORE_F32)
-        hipLaunchKernelGGL((abd_gibbs_kernel<float, true>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
-      else
-        hipLaunchKernelGGL((abd_gibbs_kernel<double, true>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
-    } else {
-      if (c->storage == ABD_STORE_F32)
-        hipLaunchKernelGGL((abd_gibbs_kernel<float, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
-      else
-        hipLaunchKernelGGL((abd_gibbs_kernel<double, false>), grid, dim3(ABD_BLOCK), lds, c->stream, ga);
-    }
-    }
-    HIP_TRY(hipGetLastError());
+    unsigned long long* stats_dev = want_stats ? c->d_counts + (size_t)c->n_slots * 2 : nullptr;
+    rc = enqueue_gibbs(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, seed, sweep, stream_offset, c->stream, c->d_counts,
+                       c->d_work, stats_dev);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(counts.data() + (size_t)k0 * 2, c->d_counts, (size_t)m * 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (ga.stats) {
+    if (stats_dev) {
       unsigned long long st[8];
-      HIP_TRY(hipMemcpy(st, ga.stats, sizeof st, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(st, stats_dev, sizeof st, hipMemcpyDeviceToHost));
       const double ni = (double)std::max<unsigned long long>(1, st[0]);
       std::fprintf(stderr, "[abd gibbs stats] individuals x chains %llu; per individual: iterations %.1f, refills %.1f, walk steps %.1f "
                    "(lanes busy %.1f of 64), tail finishes %.1f, commit scans %.1f, acceptances %.2f\n",
@@ -1297,39 +1314,25 @@ struct abd_sampler {
   int64_t rec_chunk = 0;
   double* d_rec_mu = nullptr;   // [2][n][rec_chunk][G*N]  (ab_n_mu, ab_s_mu)
   int8_t* d_rec_i8 = nullptr;   // [2][n][rec_chunk][G*N]  (i_raw, i) then [n][rec_chunk][N] (waner)
-  // scratch of one lock-step round
-  std::vector<int32_t> ids, who;
-  std::vector<double> th, lp, gr;
-  // NUTS runs the chains as two groups, each with its own launch in flight (pipe g, private result rows g): while
-  // the host feeds one group's results to its trees and builds the next leapfrog points, the other group's
-  // evaluation is running
-  struct Group {
-    int lo = 0, hi = 0, m = 0;
-    bool pending = false;
-    double tag = 0.0;
-    std::vector<int32_t> ids, who;
-    std::vector<double> th, lp, gr;
-  } grp[4];
-  int n_groups = 1;
+  std::vector<double> lp, gr;  // starting points' logp / gradient
+  int unit = 1;                // chains per independent unit (sampler_run_units)
 };
 
 namespace {
 
-int sampler_accumulate(abd_sampler* s) {
+// add chain k's Deterministics at its current point to its running sums (stream st)
+int accumulate_chain(abd_sampler* s, int k, hipStream_t st) {
   abd_ctx* c = s->c;
   const size_t cells = (size_t)c->G * c->N;
   const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
   const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-  for (int k = 0; k < s->n; ++k) {
-    EvalArgs a;
-    base_args(c, a);
-    a.n_chains = 1;
-    a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
-    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a, (int8_t*)nullptr,
-                       (double*)nullptr, (double*)nullptr, s->d_sums + (size_t)k * 3 * cells);
-    HIP_TRY(hipGetLastError());
-  }
-  s->n_accumulated += 1;
+  EvalArgs a;
+  base_args(c, a);
+  a.n_chains = 1;
+  a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
+  hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, st, a, (int8_t*)nullptr,
+                     (double*)nullptr, (double*)nullptr, s->d_sums + (size_t)k * 3 * cells);
+  HIP_TRY(hipGetLastError());
   return ABD_OK;
 }
 
@@ -1359,33 +1362,25 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   s->o = *opts;
   s->chains.assign(chains, chains + n);
   s->ch.resize((size_t)n);
-  s->ids.resize((size_t)n);
-  s->who.resize((size_t)n);
-  s->th.resize((size_t)n * ABD_N_THETA);
   s->lp.resize((size_t)n);
   s->gr.resize((size_t)n * ABD_N_THETA);
-  // up to four groups of (almost) equal size, contiguous chain ranges.  Measured (tools/probe_nuts_rate.py): two groups
-  // gain 0-10 % over one, four lose again -- an iteration lasts as long as its longest tree times the latency of one
-  // evaluation call, which more launches in flight do not shorten
-  s->n_groups = std::min(2, n);
-  if (const char* e = std::getenv("ABD_SAMPLER_GROUPS")) s->n_groups = std::max(1, std::min({4, n, std::atoi(e)}));
-  for (int g = 0, lo = 0; g < 4; ++g) {
-    abd_sampler::Group& gr = s->grp[g];
-    const int size = g < s->n_groups ? n / s->n_groups + (g < n % s->n_groups ? 1 : 0) : 0;
-    gr.lo = lo;
-    gr.hi = lo + size;
-    lo += size;
-    const size_t cap = (size_t)std::max(1, size);
-    gr.ids.resize(cap);
-    gr.who.resize(cap);
-    gr.th.resize(cap * ABD_N_THETA);
-    gr.lp.resize(cap);
-    gr.gr.resize(cap * ABD_N_THETA);
-  }
-  // a group's launch shares the chip with the other groups' launches
-  c->group_blocks = std::min(c->dense_blocks, c->n_cu * std::max(1, c->dbpc / s->n_groups));
+  // chains per unit: a large dense cohort keeps the chip busy with one chain per launch and gains most from chains
+  // that never wait for each other; a small cohort is bound by the host's ~6 us per launch, which a unit's chains share
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? 1 : std::max(2, std::min(8, (n + 3) / 4));
+  if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
+  s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
+  // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers
+  // must not depend on it
+  c->group_blocks = std::min(c->dense_blocks, c->n_cu);
   if (const char* e = std::getenv("ABD_GROUP_BLOCKS_PER_CU")) c->group_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
-  rc = abd_logp_dlogp_batch(c, n, chains, theta0, s->lp.data(), s->gr.data());
+  // the starting points through the launch shape the units will use
+  rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
+  for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
+    const int m = std::min(s->unit, n - lo);
+    rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, u % c->n_streams);
+    if (!rc) rc = wait_rows(c, kSyncSlot + u, m, c->seq, c->pipe[u % c->n_streams].st);
+    if (!rc) rc = fetch_slot(c, kSyncSlot + u, s->lp.data() + lo, s->gr.data() + (size_t)lo * ABD_N_THETA);
+  }
   if (rc) {
     delete s;
     return rc;
@@ -1431,53 +1426,238 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
 
 namespace {
 
-// copy staged draws [0, filled) of every chain to the caller's arrays, starting at draw `first`
-int record_flush(abd_sampler* s, const abd_record* rec, int64_t first, int64_t filled) {
+// copy staged draws [0, filled) of chain k to the caller's arrays, starting at draw `first` (stream st, waited for)
+int record_flush_chain(abd_sampler* s, const abd_record* rec, int k, int64_t first, int64_t filled, hipStream_t st) {
   if (filled == 0) return ABD_OK;
   abd_ctx* c = s->c;
   const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
   const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
-  for (int k = 0; k < s->n; ++k) {
-    const size_t dev = (size_t)k * s->rec_chunk, host = (size_t)k * rec->capacity + first;
-    if (rec->ab_n_mu) HIP_TRY(hipMemcpyAsync(rec->ab_n_mu + host * cells, s->d_rec_mu + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (rec->ab_s_mu) HIP_TRY(hipMemcpyAsync(rec->ab_s_mu + host * cells, s->d_rec_mu + per_var + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (rec->i_raw) HIP_TRY(hipMemcpyAsync(rec->i_raw + host * cells, s->d_rec_i8 + dev * cells, filled * cells, hipMemcpyDeviceToHost, c->stream));
-    if (rec->i) HIP_TRY(hipMemcpyAsync(rec->i + host * cells, s->d_rec_i8 + per_var + dev * cells, filled * cells, hipMemcpyDeviceToHost, c->stream));
-    if (rec->ab_s_waner) HIP_TRY(hipMemcpyAsync(rec->ab_s_waner + host * N, s->d_rec_i8 + 2 * per_var + dev * N, filled * N, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t dev = (size_t)k * s->rec_chunk, host = (size_t)k * rec->capacity + first;
+  if (rec->ab_n_mu) HIP_TRY(hipMemcpyAsync(rec->ab_n_mu + host * cells, s->d_rec_mu + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (rec->ab_s_mu) HIP_TRY(hipMemcpyAsync(rec->ab_s_mu + host * cells, s->d_rec_mu + per_var + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (rec->i_raw) HIP_TRY(hipMemcpyAsync(rec->i_raw + host * cells, s->d_rec_i8 + dev * cells, filled * cells, hipMemcpyDeviceToHost, st));
+  if (rec->i) HIP_TRY(hipMemcpyAsync(rec->i + host * cells, s->d_rec_i8 + per_var + dev * cells, filled * cells, hipMemcpyDeviceToHost, st));
+  if (rec->ab_s_waner) HIP_TRY(hipMemcpyAsync(rec->ab_s_waner + host * N, s->d_rec_i8 + 2 * per_var + dev * N, filled * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return ABD_OK;
 }
 
-// stage the current draw of every chain at position `pos` of the chunk (all asynchronous on the stream)
-int record_stage(abd_sampler* s, const abd_record* rec, int64_t pos) {
+// stage the current draw of chain k at position `pos` of its chunk (all asynchronous on stream st)
+int record_stage_chain(abd_sampler* s, const abd_record* rec, int k, int64_t pos, hipStream_t st) {
   abd_ctx* c = s->c;
   const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
   const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
   const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
   const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-  for (int k = 0; k < s->n; ++k) {
-    const size_t at = ((size_t)k * s->rec_chunk + pos);
-    const ChainSlot& slot = c->slots[(size_t)s->chains[(size_t)k]];
-    if (rec->i || rec->ab_n_mu || rec->ab_s_mu) {
-      EvalArgs a;
-      base_args(c, a);
-      a.n_chains = 1;
-      a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
-      hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, c->stream, a,
-                         rec->i ? s->d_rec_i8 + per_var + at * cells : (int8_t*)nullptr,
-                         rec->ab_n_mu ? s->d_rec_mu + at * cells : (double*)nullptr,
-                         rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, (double*)nullptr);
-      HIP_TRY(hipGetLastError());
-    }
-    if (rec->i_raw) {
-      dim3 grid((c->N + 255) / 256, c->G);
-      hipLaunchKernelGGL(abd_unpack_bits_kernel, grid, dim3(256), 0, c->stream, slot.rw, s->d_rec_i8 + at * cells, c->G, c->N);
-      HIP_TRY(hipGetLastError());
-    }
-    if (rec->ab_s_waner)
-      HIP_TRY(hipMemcpyAsync(s->d_rec_i8 + 2 * per_var + at * N, slot.waner, N, hipMemcpyDeviceToDevice, c->stream));
+  const size_t at = ((size_t)k * s->rec_chunk + pos);
+  const ChainSlot& slot = c->slots[(size_t)s->chains[(size_t)k]];
+  if (rec->i || rec->ab_n_mu || rec->ab_s_mu) {
+    EvalArgs a;
+    base_args(c, a);
+    a.n_chains = 1;
+    a.ch[0] = chain_par(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q);
+    hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, st, a,
+                       rec->i ? s->d_rec_i8 + per_var + at * cells : (int8_t*)nullptr,
+                       rec->ab_n_mu ? s->d_rec_mu + at * cells : (double*)nullptr,
+                       rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, (double*)nullptr);
+    HIP_TRY(hipGetLastError());
   }
+  if (rec->i_raw) {
+    dim3 grid((c->N + 255) / 256, c->G);
+    hipLaunchKernelGGL(abd_unpack_bits_kernel, grid, dim3(256), 0, st, slot.rw, s->d_rec_i8 + at * cells, c->G, c->N);
+    HIP_TRY(hipGetLastError());
+  }
+  if (rec->ab_s_waner)
+    HIP_TRY(hipMemcpyAsync(s->d_rec_i8 + 2 * per_var + at * N, slot.waner, N, hipMemcpyDeviceToDevice, st));
+  return ABD_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// The sampler's chains run as independent UNITS of `unit` consecutive chains (1 for large dense cohorts, 4 otherwise;
+// abd_sampler_create), unit u on HIP stream u mod 8 with its own private result rows (slot kSyncSlot + u):
+//   tree:      one evaluation launch per leapfrog for the unit's chains whose tree is still growing
+//   sweep:     when all its trees have stopped, the unit's Gibbs sweep and the evaluation at the new state are queued
+//              back to back on its stream (stream order: no host wait in between), counts copied to pinned memory
+//   recording: queued on the same stream behind them
+// The host polls the completion tags of whatever is in flight and moves each unit's state machine on.  No unit waits
+// for another one's trees -- in lock step an iteration lasts as long as the LONGEST tree of all chains -- and the
+// units' launches overlap on the device.  Within a unit the chains share launches (small cohorts are launch-bound:
+// ~6 us of host time per evaluation launch).  Same compound step per chain, same random streams, and the numbers a
+// unit's launch produces depend only on the unit (fixed grid), never on the other units or on timing.
+int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec, bool recording) {
+  abd_ctx* c = s->c;
+  const int n = s->n, B = s->unit;
+  const int n_units = (n + B - 1) / B;
+  enum { EVAL, POST, DONE };
+  struct Unit {
+    int lo = 0, hi = 0, m = 0, state = EVAL;
+    int64_t k = 0;       // iterations completed in this call
+    int64_t staged = 0;  // draws staged on the device, not yet copied out
+    int64_t flushed_to = 0;
+    double tag = 0.0;
+    std::vector<int32_t> ids, who;
+    std::vector<double> th, lp, gr;
+  };
+  std::vector<Unit> units((size_t)n_units);
+  HIP_TRY(hipSetDevice(c->device));
+  if (int frc = flush_ring(c)) return frc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first
+  auto stream_of = [&](int u) { return c->pipe[u % c->n_streams].st; };
+  // evaluate the points th[0 .. m) of the unit's chains who[0 .. m)
+  auto launch_eval = [&](int u) -> int {
+    Unit& un = units[(size_t)u];
+    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, u % c->n_streams);
+    if (rc) return rc;
+    un.tag = c->seq;
+    return ABD_OK;
+  };
+  auto launch_tree = [&](int u) -> int {  // the next leapfrog of every tree of the unit that is still growing
+    Unit& un = units[(size_t)u];
+    un.m = 0;
+    for (int j = un.lo; j < un.hi; ++j) {
+      abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+      if (!nu.active) continue;
+      un.ids[(size_t)un.m] = s->chains[(size_t)j];
+      un.who[(size_t)un.m] = j;
+      std::memcpy(un.th.data() + (size_t)un.m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
+      ++un.m;
+    }
+    return un.m ? launch_eval(u) : ABD_OK;
+  };
+  auto ready = [&](int u) -> bool {  // have all result rows of the unit's launch landed? (never blocks)
+    const Unit& un = units[(size_t)u];
+    volatile const double* rows = c->h_out + (size_t)(kSyncSlot + u) * c->n_slots * ABD_NOUT;
+    for (int k = un.m - 1; k >= 0; --k)
+      if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] != un.tag) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
+  };
+  // end of iteration un.k of the unit's chains (points and discrete states are final): outputs, running sums, recording;
+  // then the next iteration's first leapfrogs, or DONE
+  auto finish_iteration = [&](int u, bool with_counts) -> int {
+    Unit& un = units[(size_t)u];
+    hipStream_t st = stream_of(u);
+    const bool draw = s->it + un.k >= s->o.tune;
+    for (int j = un.lo; j < un.hi; ++j) {
+      const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+      if (theta) std::memcpy(theta + ((size_t)j * n_iter + un.k) * ABD_N_THETA, nu.q, sizeof(double) * ABD_N_THETA);
+      if (stats) {
+        double* o = stats + ((size_t)j * n_iter + un.k) * ABD_N_STATS;
+        o[ABD_STAT_LP] = nu.lp;
+        o[ABD_STAT_TREE_DEPTH] = nu.stats.tree_depth;
+        o[ABD_STAT_N_STEPS] = nu.stats.n_steps;
+        o[ABD_STAT_MEAN_TREE_ACCEPT] = nu.stats.mean_tree_accept;
+        o[ABD_STAT_STEP_SIZE] = nu.stats.step_size;
+        o[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
+        o[ABD_STAT_ENERGY] = nu.stats.energy;
+        o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
+        o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
+        o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+      }
+      if (draw && s->d_sums)
+        if (int rc = accumulate_chain(s, j, st)) return rc;
+      if (recording)
+        if (int rc = record_stage_chain(s, rec, j, un.staged, st)) return rc;
+    }
+    if (recording && ++un.staged == s->rec_chunk) {
+      for (int j = un.lo; j < un.hi; ++j)
+        if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
+      un.flushed_to += un.staged;
+      un.staged = 0;
+    }
+    un.k += 1;
+    if (un.k == n_iter) {
+      un.state = DONE;
+      if (recording)
+        for (int j = un.lo; j < un.hi; ++j)
+          if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
+      return ABD_OK;
+    }
+    for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
+    un.state = EVAL;
+    return launch_tree(u);
+  };
+  for (int u = 0; u < n_units; ++u) {
+    Unit& un = units[(size_t)u];
+    un.lo = u * B;
+    un.hi = std::min(n, un.lo + B);
+    const size_t cap = (size_t)(un.hi - un.lo);
+    un.ids.resize(cap);
+    un.who.resize(cap);
+    un.th.resize(cap * ABD_N_THETA);
+    un.lp.resize(cap);
+    un.gr.resize(cap * ABD_N_THETA);
+    un.flushed_to = recording ? rec->first : 0;
+    if (n_iter == 0) {
+      un.state = DONE;
+      continue;
+    }
+    for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
+    if (int rc = launch_tree(u)) return rc;
+  }
+  for (long spins = 0;;) {
+    bool any = false, progressed = false;
+    for (int u = 0; u < n_units; ++u) {
+      Unit& un = units[(size_t)u];
+      if (un.state == DONE) continue;
+      any = true;
+      if (!ready(u)) continue;
+      progressed = true;
+      if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
+      if (un.state == EVAL) {
+        for (int q = 0; q < un.m; ++q)
+          s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+        if (int rc = launch_tree(u)) return rc;
+        if (un.m) continue;  // some tree of the unit is still growing
+        for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
+        if (!s->o.gibbs) {
+          if (int rc = finish_iteration(u, false)) return rc;
+          continue;
+        }
+        // binary Gibbs-Metropolis on [i_raw, ab_s_waner] of the unit's chains, then logp and gradient at the new
+        // states: queued back to back on the unit's stream
+        hipStream_t st = stream_of(u);
+        un.m = un.hi - un.lo;
+        for (int j = un.lo; j < un.hi; ++j) {
+          un.ids[(size_t)(j - un.lo)] = s->chains[(size_t)j];
+          un.who[(size_t)(j - un.lo)] = j;
+          std::memcpy(un.th.data() + (size_t)(j - un.lo) * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
+        }
+        if (int rc = enqueue_gibbs(c, un.m, un.ids.data(), un.th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + un.k),
+                                   (uint32_t)s->o.chain_offset, st, c->d_counts_chain + 2 * (size_t)un.lo,
+                                   c->d_work + c->n_slots + un.lo, nullptr))
+          return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)un.lo, c->d_counts_chain + 2 * (size_t)un.lo,
+                               (size_t)un.m * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        un.state = POST;
+        if (int rc = launch_eval(u)) return rc;
+      } else {  // POST: the sweep and the evaluation behind it are done (the counts landed before: same stream)
+        for (int q = 0; q < un.m; ++q)
+          s->ch[(size_t)un.who[(size_t)q]].nuts.set_point(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+        if (int rc = finish_iteration(u, true)) return rc;
+      }
+    }
+    if (!any) break;
+    if (progressed) {
+      spins = 0;
+    } else if (++spins > 4000000) {
+      c->wait_fallbacks++;  // no tag for tens of ms: synchronise the streams in flight (see abd_wait_fallbacks)
+      for (int u = 0; u < n_units; ++u)
+        if (units[(size_t)u].state != DONE) HIP_TRY(hipStreamSynchronize(stream_of(u)));
+      spins = 0;
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  // the context's stream continues behind everything the units queued
+  for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;
+  if (int jrc = join_pipes(c)) return jrc;
+  const int64_t first_draw = std::max<int64_t>(s->it, s->o.tune);
+  if (s->d_sums && s->it + n_iter > first_draw) s->n_accumulated += s->it + n_iter - first_draw;
+  s->it += n_iter;
   return ABD_OK;
 }
 
@@ -1510,122 +1690,7 @@ int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double
       s->d_rec_i8 = i8;
     }
   }
-  int64_t staged = 0, flushed_to = recording ? rec->first : 0;
-  std::vector<int64_t> acc((size_t)n, 0), prop((size_t)n, 0);
-  for (int64_t k = 0; k < n_iter; ++k) {
-    // ---- NUTS: the chains of a group advance one leapfrog per launch until every tree has stopped; the two groups'
-    // launches overlap (a chain's trajectory does not depend on the other group: own random stream, own rows) ----
-    for (auto& a : s->ch) a.begin();
-    auto launch = [&](int g) -> int {
-      abd_sampler::Group& gr = s->grp[g];
-      gr.m = 0;
-      gr.pending = false;
-      for (int j = gr.lo; j < gr.hi; ++j) {
-        abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
-        if (!nu.active) continue;
-        gr.ids[(size_t)gr.m] = s->chains[(size_t)j];
-        gr.who[(size_t)gr.m] = j;
-        std::memcpy(gr.th.data() + (size_t)gr.m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
-        ++gr.m;
-      }
-      if (gr.m == 0) return ABD_OK;
-      int rc = enqueue_slot(c, kSyncSlot + g, gr.m, gr.ids.data(), gr.th.data(), true, false, g);
-      if (rc) return rc;
-      gr.tag = c->seq;
-      gr.pending = true;
-      return ABD_OK;
-    };
-    auto ready = [&](int g) -> bool {  // have all result rows of the group's launch landed? (never blocks)
-      const abd_sampler::Group& gr = s->grp[g];
-      volatile const double* rows = c->h_out + (size_t)(kSyncSlot + g) * c->n_slots * ABD_NOUT;
-      const int first = ((gr.m - 1) / ABD_MAX_BATCH) * ABD_MAX_BATCH;
-      for (int k = gr.m - 1; k >= first; --k)
-        if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] != gr.tag) return false;
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return true;
-    };
-    auto complete = [&](int g) -> int {
-      abd_sampler::Group& gr = s->grp[g];
-      if (int frc = fetch_slot(c, kSyncSlot + g, gr.lp.data(), gr.gr.data())) return frc;
-      for (int j = 0; j < gr.m; ++j)
-        s->ch[(size_t)gr.who[(size_t)j]].nuts.feed(gr.lp[(size_t)j], gr.gr.data() + (size_t)j * ABD_N_THETA);
-      return ABD_OK;
-    };
-    HIP_TRY(hipSetDevice(c->device));
-    if (int frc = flush_ring(c)) return frc;
-    for (int g = 0; g < s->n_groups; ++g)
-      if (int rc = launch(g)) return rc;
-    for (long spins = 0;;) {
-      bool any = false, progressed = false;
-      for (int g = 0; g < s->n_groups; ++g) {
-        if (!s->grp[g].pending) continue;
-        any = true;
-        if (!ready(g)) continue;
-        if (int rc = complete(g)) return rc;
-        if (int rc = launch(g)) return rc;
-        progressed = true;
-      }
-      if (!any) break;
-      if (progressed) {
-        spins = 0;
-      } else if (++spins > 4000000) {
-        // no tag for tens of ms: fall back to synchronising the groups' streams (counted, see abd_wait_fallbacks)
-        c->wait_fallbacks++;
-        for (int g = 0; g < s->n_groups; ++g)
-          if (s->grp[g].pending) HIP_TRY(hipStreamSynchronize(c->pipe[g].st));
-        spins = 0;
-      } else {
-        __builtin_ia32_pause();
-      }
-    }
-    const bool draw = s->it >= s->o.tune;
-    for (auto& a : s->ch) a.end_transition();
-    // ---- binary Gibbs-Metropolis on [i_raw, ab_s_waner], then logp and gradient at the new state ----
-    if (s->o.gibbs) {
-      for (int j = 0; j < n; ++j)
-        std::memcpy(s->th.data() + (size_t)j * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
-      int rc = gibbs_sweep_impl(c, n, s->chains.data(), s->th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)s->it,
-                                (uint32_t)s->o.chain_offset, acc.data(), prop.data());
-      if (rc) return rc;
-      rc = abd_logp_dlogp_batch(c, n, s->chains.data(), s->th.data(), s->lp.data(), s->gr.data());
-      if (rc) return rc;
-      for (int j = 0; j < n; ++j) s->ch[(size_t)j].nuts.set_point(s->lp[(size_t)j], s->gr.data() + (size_t)j * ABD_N_THETA);
-    }
-    for (int j = 0; j < n; ++j) {
-      const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
-      if (theta) std::memcpy(theta + ((size_t)j * n_iter + k) * ABD_N_THETA, nu.q, sizeof(double) * ABD_N_THETA);
-      if (stats) {
-        double* r = stats + ((size_t)j * n_iter + k) * ABD_N_STATS;
-        r[ABD_STAT_LP] = nu.lp;
-        r[ABD_STAT_TREE_DEPTH] = nu.stats.tree_depth;
-        r[ABD_STAT_N_STEPS] = nu.stats.n_steps;
-        r[ABD_STAT_MEAN_TREE_ACCEPT] = nu.stats.mean_tree_accept;
-        r[ABD_STAT_STEP_SIZE] = nu.stats.step_size;
-        r[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
-        r[ABD_STAT_ENERGY] = nu.stats.energy;
-        r[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
-        r[ABD_STAT_GIBBS_ACCEPTED] = (double)acc[(size_t)j];
-        r[ABD_STAT_GIBBS_PROPOSED] = (double)prop[(size_t)j];
-      }
-    }
-    if (draw && s->d_sums) {
-      int rc = sampler_accumulate(s);
-      if (rc) return rc;
-    }
-    if (recording) {
-      int rc = record_stage(s, rec, staged);
-      if (rc) return rc;
-      if (++staged == s->rec_chunk) {
-        rc = record_flush(s, rec, flushed_to, staged);
-        if (rc) return rc;
-        flushed_to += staged;
-        staged = 0;
-      }
-    }
-    s->it += 1;
-  }
-  if (recording) return record_flush(s, rec, flushed_to, staged);
-  return ABD_OK;
+  return sampler_run_units(s, n_iter, theta, stats, rec, recording);
 }
 
 int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* mu_n_mean, double* mu_s_mean, int64_t* n_draws) {

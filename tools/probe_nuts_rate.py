@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """logp+grad evaluations per second AS THE NATIVE SAMPLER SEES THEM (NUTS only, no sweep): leapfrogs of all chains
 per wall second inside abd_sampler_run.  usage: probe_nuts_rate.py [c3|c2|default] [chains] [iterations]
-ABD_SAMPLER_GROUPS=1 runs all chains as one lock-step group (one launch in flight), the default is two groups."""
+ABD_SAMPLER_UNIT=B sets the chains per independent unit (default: 1 for large dense cohorts, 2-8 otherwise)."""
 import os
 import sys
 import time
@@ -40,6 +40,6 @@ t0 = time.perf_counter()
 _, st = smp.run(iters)
 dt = time.perf_counter() - t0
 evals = float(st["n_steps"].sum())
-print(f"{cfg} chains={C} groups={os.environ.get('ABD_SAMPLER_GROUPS', '2')}: {evals / dt:,.0f} evals/s as seen by NUTS "
-      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms per lock-step iteration)")
+print(f"{cfg} chains={C} unit={os.environ.get('ABD_SAMPLER_UNIT', 'auto')}: {evals / dt:,.0f} evals/s as seen by NUTS "
+      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains)")
 smp.close()

@@ -1366,7 +1366,9 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   s->gr.resize((size_t)n * ABD_N_THETA);
   // chains per unit: a large dense cohort keeps the chip busy with one chain per launch and gains most from chains
   // that never wait for each other; a small cohort is bound by the host's ~6 us per launch, which a unit's chains share
-  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? 1 : std::max(2, std::min(8, (n + 3) / 4));
+  // (measured, tools/probe_nuts_rate.py: config 3 -- 8 chains 88 k evals/s with units of 1, 82 k with 4; 16 chains 92 k / 112 k;
+  // default cohort, 16 chains -- 152 k with units of 1, 334 k with 4, 359 k with 8)
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(2, std::min(8, (n + 3) / 4));
   if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
   // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers

@@ -31,7 +31,10 @@ extern "C" {
 #endif
 
 #define ABD_N_THETA 17
-#define ABD_MAX_GAPS 256  /* gap axis is held as 4 x 64-bit wave-uniform masks */
+/* Limit of this library that the reference does not have: abdpymc takes any n_gaps (abd.py:101, 224-239); here an
+ * individual's gap axis is held as 4 x 64-bit packed words in registers, so n_gaps <= 256 (abd_create refuses more with
+ * ABD_ERR_ARG).  The reference's cohorts have 26 / 31 monthly gaps, BASELINE's synthetic ones 60 / 200. */
+#define ABD_MAX_GAPS 256
 #define ABD_MAX_BATCH 16  /* chains per kernel launch (larger batches are split) */
 
 typedef enum {
@@ -148,11 +151,15 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
 
 /* ---------------------------------------------------------------------------------------------------
  * The compound step pm.sample assigns to this model (reference call site abd.py:921-922), run natively
- * for several chains in lock step: NUTS on the 17 continuous variables -- every chain's pending leapfrog
- * point is evaluated in ONE abd_logp_dlogp_batch launch -- then one abd_gibbs_sweep over all chains, then
- * one batched re-evaluation at the new discrete state.  This removes the host-language cost per leapfrog
- * (PyMC: Python).  Step size: dual averaging to `target_accept`; metric: diagonal,
- * windowed running variance of the tuning draws (abdpymc_amd/csrc/abd_nuts.hpp).
+ * for several chains: NUTS on the 17 continuous variables, then one Gibbs sweep of [i_raw, ab_s_waner], then a
+ * re-evaluation at the new discrete state.  This removes the host-language cost per leapfrog (PyMC: Python;
+ * SURVEY 8f rank 4).  The chains run as independent units of 1-8 consecutive chains, each on its own HIP stream
+ * with its own result rows: a unit's pending leapfrog points go out as ONE evaluation launch, its sweep and the
+ * re-evaluation are queued behind each other on its stream, and the host polls completion tags -- no unit waits
+ * for another one's trees (as PyMC's one process per chain does not), and their launches overlap on the device.
+ * What a unit computes depends only on the unit (fixed launch shape), never on the other units or on timing.
+ * Step size: dual averaging to `target_accept`; metric: diagonal, windowed running variance of the tuning draws
+ * (abdpymc_amd/csrc/abd_nuts.hpp).
  * Iterations [0, tune) adapt; later ones are draws.  Randomness: one xoshiro256++ stream per chain keyed by
  * (seed, chain slot) for NUTS; Philox keyed by (seed, iteration) for the sweep. */
 typedef struct abd_sampler abd_sampler;

@@ -39,9 +39,9 @@ def test_bench_line_has_the_contract_fields():
     # the entry that carries frac describes the launch shape that was timed: its device time per launch cannot
     # exceed the host's time per step (which adds the wait and the fetch)
     assert ro["kernel_us"] <= d["ms_per_step"] * 1e3 * 1.02, (ro["kernel_us"], d["ms_per_step"])
-    assert ro["launches"] % 40 == 0
+    assert ro["launches"] % 40 == 0 and ro["launches"] >= 120
     iso = ro["isolated"]
-    assert iso["kernel_us"] > 0 and abs(iso["frac"] - iso["achieved"] / 8000.0) < 1e-3 and iso["launches"] == 40
+    assert iso["kernel_us"] > 0 and abs(iso["frac"] - iso["achieved"] / 8000.0) < 1e-3 and iso["launches"] % 40 == 0
     if ro["valu"] is not None:
         assert ro["valu"]["peak"] == 78.6 and 0 < ro["valu"]["frac"] < 1.2
     cb = d["cpu_baseline"]

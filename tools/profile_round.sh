@@ -32,3 +32,22 @@ for cfg in $CFGS; do
   rm -rf "$OUT/${cfg}_trace" "$OUT/${cfg}_trace1" "$OUT/${cfg}_pmc_sq" "$OUT/${cfg}_pmc_fetch" "$OUT/${cfg}_pmc_write"
 done
 ls -la "$OUT"
+# ---- the Gibbs sweep (config 3, 4 chains): time, scheduler statistics, SQ counters; random state and converged state ----
+if [ "${GIBBS:-1}" = "1" ]; then
+  for mode in random truth; do
+    arg=""; [ $mode = truth ] && arg="truth"
+    python3 tools/probe_gibbs.py 10 $arg > "$OUT/gibbs_${mode}_time.txt" 2>&1
+    ABD_GIBBS_STATS=1 python3 tools/probe_gibbs.py 2 $arg > "$OUT/gibbs_${mode}_stats.txt" 2>&1
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$OUT/gibbs_pmc" --output-format csv -- python3 tools/probe_gibbs.py 3 $arg > "$OUT/gibbs_pmc.log" 2>&1
+    python3 tools/pmc_summary.py "$OUT/gibbs_pmc" gibbs > "$OUT/gibbs_${mode}_pmc_sq.txt" 2>&1
+    rm -rf "$OUT/gibbs_pmc"
+    ABD_GIBBS_V1=1 python3 tools/probe_gibbs.py 10 $arg > "$OUT/gibbs_${mode}_time_wave_per_proposal_kernel.txt" 2>&1
+  done
+  for c in 4 8 16; do python3 tools/probe_nuts_rate.py c3 $c 40; done > "$OUT/nuts_rate_c3.txt" 2>&1
+  for c in 4 16; do python3 tools/probe_nuts_rate.py default $c 300; done > "$OUT/nuts_rate_default_cohort.txt" 2>&1
+  python3 tools/bench_sampler.py default --chains 4 --tune 1000 --draws 1000 > "$OUT/sampler_default_cohort.txt" 2>&1
+  python3 tools/bench_sampler.py default --chains 4 --tune 1000 --draws 1000 --dense >> "$OUT/sampler_default_cohort.txt" 2>&1
+  python3 tools/bench_sampler.py default --chains 16 --tune 1000 --draws 1000 --no-record >> "$OUT/sampler_default_cohort.txt" 2>&1
+  python3 tools/bench_sampler.py c3 --chains 4 --tune 100 --draws 100 --no-record > "$OUT/sampler_c3.txt" 2>&1
+fi
+ls "$OUT" | wc -l

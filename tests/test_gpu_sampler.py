@@ -1,5 +1,5 @@
 """
-The native compound sampler (abd_sampler_*: lock-step NUTS over the chains + device Gibbs sweep) on the GPU.
+The native compound sampler (abd_sampler_*: NUTS + device Gibbs sweep, the chains as independent units) on the GPU.
 
 NUTS draws cannot be compared with PyMC's (not importable offline; parity of the *sampler* is statistical,
 parity of every logp / gradient / sweep it consumes is tested elsewhere).  What is pinned here:
@@ -390,3 +390,71 @@ def test_run_record_equals_draw_by_draw_readback(test_td):
     with pytest.raises(ValueError):
         c2.run_record(1, 0, i=np.zeros((2, 3, G, N)))  # wrong dtype
     m.close()
+
+
+def test_a_chains_draws_do_not_depend_on_how_the_chains_are_grouped(test_td, monkeypatch):
+    """The sampler runs its chains as independent units of 1-8 chains, each with its own launches in flight.  On the
+    reference's cohorts (observation lists: a chain's sums never see the rest of a launch) a chain's draws -- continuous
+    and discrete -- must be bit-identical whatever the unit size, and whether 2 or 5 chains run beside it."""
+    from abdpymc_amd.model import model
+
+    def run(n_chains, unit):
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", str(unit))
+        m = model(test_td, splits=(14,), n_chains=n_chains)
+        q0 = _start(m, n_chains, seed=3)
+        smp = m.ctx.sampler(np.arange(n_chains), q0, tune=25, seed=9)
+        th, st = smp.run(40)
+        states = [m.ctx.get_discrete(c) for c in range(n_chains)]
+        smp.close()
+        m.close()
+        return th, st, states
+
+    th1, st1, s1 = run(5, 1)
+    for n_chains, unit in ((5, 2), (5, 4), (5, 8), (2, 1), (2, 2)):
+        th, st, ss = run(n_chains, unit)
+        np.testing.assert_array_equal(th, th1[:n_chains])
+        np.testing.assert_array_equal(st["gibbs_accepted"], st1["gibbs_accepted"][:n_chains])
+        for c in range(n_chains):
+            np.testing.assert_array_equal(ss[c][0], s1[c][0])
+            np.testing.assert_array_equal(ss[c][1], s1[c][1])
+    assert len({tuple(th1[c, -1]) for c in range(5)}) == 5
+
+
+def test_units_on_a_dense_cohort_are_deterministic_and_record_like_a_twin_run():
+    """Dense cohort (the dense evaluation kernel and the lane-per-proposal sweep), 3 chains as 3 units: two runs give the
+    same bits; recording while running does not perturb the chains; every recorded `i` is the constrained `i_raw` of
+    the same draw and the recorded lp is the joint logp there."""
+    from abdpymc_amd._native import Context
+
+    sc = synthetic.make_cohort(300, 40, seed=4)
+    coh = oracle_cohort_from_synth(sc)
+    G, N, C = 40, 300, 3
+
+    def run(record):
+        ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=(17,), n_chains=C)
+        q0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+        for c in range(C):
+            ctx.set_discrete(c, *synthetic.make_chain_state(N, G, c))
+        smp = ctx.sampler(np.arange(C), q0, tune=10, seed=2)
+        rec = {}
+        if record:
+            rec = dict(i_raw=np.zeros((C, 14, G, N), np.int8), i=np.zeros((C, 14, G, N), np.int8), ab_s_waner=np.zeros((C, 14, N), np.int8))
+            th, st = smp.run_record(14, 0, **rec)
+        else:
+            th, st = smp.run(14)
+        smp.close()
+        ctx.close()
+        return th, st, rec
+
+    th_a, st_a, _ = run(False)
+    th_b, st_b, rec = run(True)
+    th_c, _, _ = run(False)
+    np.testing.assert_array_equal(th_a, th_c)
+    np.testing.assert_array_equal(th_a, th_b)
+    np.testing.assert_array_equal(st_a["lp"], st_b["lp"])
+    for c in range(C):
+        for k in (0, 7, 13):
+            i_ref = O.constrain_infections(rec["i_raw"][c, k], np.asarray(sc.pcrpos).T, (17,))
+            np.testing.assert_array_equal(rec["i"][c, k], i_ref)
+            lp = O.logp_dlogp(th_b[c, k], rec["i_raw"][c, k], rec["ab_s_waner"][c, k], coh, (17,))[0]
+            assert abs(lp - st_b["lp"][c, k]) <= 1e-9 * abs(lp)

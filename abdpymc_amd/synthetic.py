@@ -87,6 +87,18 @@ TRUTH = dict(ab_n_init=-2.0, ab_s_init=-2.0, ab_n_perm=2.0, ab_s_perm=2.0, ab_n_
              it_n_b=-2.2, it_s_b=-2.2, it_n_d=1.6, it_s_d=1.6, it_n_sigma=0.1, it_s_sigma=0.1)
 
 
+def truth_theta(n_gaps: int) -> np.ndarray:
+    """The unconstrained 17-vector at the simulation's own parameters (a converged chain's neighbourhood)."""
+
+    def logit(p):
+        return math.log(p / (1.0 - p))
+
+    T = TRUTH
+    return np.array([logit(1.0 / n_gaps), math.log(T["ab_n_perm"]), math.log(T["ab_n_temp"]), logit(T["ab_n_rho"]), T["ab_n_init"],
+                     math.log(T["ab_s_perm"]), logit(T["ab_s_rho"]), logit(0.99), 0.0, 0.0, T["ab_s_init"],
+                     T["it_n_b"], T["it_n_d"], math.log(T["it_n_sigma"]), T["it_s_b"], T["it_s_d"], math.log(T["it_s_sigma"])])
+
+
 def make_cohort(n_inds: int, n_gaps: int, seed: int = SEED) -> SyntheticCohort:
     rng = np.random.default_rng(seed)
     G, N = n_gaps, n_inds

@@ -16,12 +16,7 @@ for c in range(C):
 th = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
 if len(sys.argv) > 2 and sys.argv[2] == "truth":
     # a converged chain: the simulation's own parameters and infections
-    import math
-    T = synthetic.TRUTH
-    logit = lambda p: math.log(p / (1 - p))
-    t = np.array([logit(1.0 / G), math.log(T["ab_n_perm"]), math.log(T["ab_n_temp"]), logit(T["ab_n_rho"]), T["ab_n_init"],
-                  math.log(T["ab_s_perm"]), logit(T["ab_s_rho"]), logit(0.99), 0.0, 0.0, T["ab_s_init"],
-                  T["it_n_b"], T["it_n_d"], math.log(T["it_n_sigma"]), T["it_s_b"], T["it_s_d"], math.log(T["it_s_sigma"])])
+    t = synthetic.truth_theta(G)
     th = np.tile(t, (C, 1))
     for c in range(C):
         ctx.set_discrete(c, sc.i_true, np.ones(N, dtype=np.int8))

@@ -93,6 +93,13 @@ struct abd_ctx {
   uint64_t* vw = nullptr;  // [nt][N]
   uint64_t* pw = nullptr;  // [nt][N]
   double* exp2_tab = nullptr;  // dense cohorts: 2^(j/1024) (abd_dense.hpp)
+  // dense kernel: how a launch shape (grid.x, ranges per workgroup) cuts the (lane group, gap) plane into ranges, built on
+  // first use and kept: {first lane group, first gap, rows, 0} per range
+  struct RangeTable {
+    int blocks = 0, nsub = 0;
+    int32_t* dev = nullptr;
+  };
+  std::vector<RangeTable> range_tables;
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
   // A pipe = a HIP stream with its own pair of partial buffers and its own pending fixed-order sum.  Pipe 0 is
@@ -406,6 +413,38 @@ int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
   return (int)std::max<int64_t>(1, std::min<int64_t>({want, cap, (int64_t)c->blocks_max}));
 }
 
+// The ranges of a dense launch of `blocks` workgroups x `nsub` ranges each: equal shares (+-1) of the n_lg x G rows; with
+// one range per workgroup (nsub == 1) the first ABD_MAX_BATCH ranges -- the workgroups that may carry the fused
+// fixed-order sum of an earlier launch -- are fin_rows shorter and the others share the difference.
+int range_table(abd_ctx* c, int blocks, int nsub, const int32_t** out) {
+  for (const auto& rt : c->range_tables)
+    if (rt.blocks == blocks && rt.nsub == nsub) {
+      *out = rt.dev;
+      return ABD_OK;
+    }
+  const int64_t rows_total = (int64_t)c->n_lg * c->G, n_ranges = (int64_t)blocks * nsub;
+  const int64_t n_short = nsub == 1 ? std::min<int64_t>(ABD_MAX_BATCH, n_ranges) : 0;
+  const int64_t e_fin = (nsub == 1 && (rows_total + n_short * c->fin_rows) / n_ranges >= 2 * c->fin_rows) ? c->fin_rows : 0;
+  const int64_t virt = rows_total + n_short * e_fin;
+  auto start = [&](int64_t r) { return r * virt / n_ranges - e_fin * std::min(r, n_short); };
+  std::vector<int32_t> tab((size_t)n_ranges * 4);
+  for (int64_t r = 0; r < n_ranges; ++r) {
+    const int64_t pos = start(r), end = start(r + 1);
+    tab[(size_t)r * 4 + 0] = (int32_t)(pos / c->G);
+    tab[(size_t)r * 4 + 1] = (int32_t)(pos % c->G);
+    tab[(size_t)r * 4 + 2] = (int32_t)std::max<int64_t>(0, end - pos);
+    tab[(size_t)r * 4 + 3] = 0;
+  }
+  abd_ctx::RangeTable rt;
+  rt.blocks = blocks;
+  rt.nsub = nsub;
+  HIP_TRY(hipMalloc(&rt.dev, tab.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(rt.dev, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->range_tables.push_back(rt);
+  *out = rt.dev;
+  return ABD_OK;
+}
+
 // queue the standalone fixed-order sum of a launch whose partials are still pending
 int flush_pipe(abd_ctx* c, int pi) {
   abd_ctx::Pipe& p = c->pipe[pi];
@@ -462,6 +501,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);
   }
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
+  if (c->dense && !lanes)
+    if (int rrc = range_table(c, blocks, ABD_WAVES_PER_BLOCK / cpw, &a.range_tab)) return rrc;
   dim3 grid(blocks, n / cpw);
   int pi = 0;
   if (force_pipe >= 0) {
@@ -726,6 +767,8 @@ void free_ctx(abd_ctx* c) {
   if (c->vw) (void)hipFree(c->vw);
   if (c->pw) (void)hipFree(c->pw);
   if (c->exp2_tab) (void)hipFree(c->exp2_tab);
+  for (auto& rt : c->range_tables)
+    if (rt.dev) (void)hipFree(rt.dev);
   if (c->stage_gn) (void)hipFree(c->stage_gn);
   for (auto& s : c->slots) {
     if (s.rw) (void)hipFree(s.rw);

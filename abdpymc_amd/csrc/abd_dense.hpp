@@ -167,21 +167,17 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     __syncthreads();  // the scratch becomes the power tables
   }
 
-  // this wave's range of the flattened (lane group, gap) plane.  The workgroups that may carry a fused sum
-  // (the first n_chains of grid row 0; one range per workgroup only: CB == 4) get ranges fin_rows shorter,
-  // the others share the difference.  The split depends only on the launch shape, never on whether a sum is
-  // actually carried, so results are bit-identical either way.
-  const int64_t rows_total = (int64_t)a.n_lg * G;
-  const int64_t n_ranges = (int64_t)gridDim.x * NSUB;
-  const int64_t r = (int64_t)blk * NSUB + sub;
-  const int64_t n_short = blockIdx.y == 0 ? min((int64_t)a.n_chains, n_ranges) : 0;
-  const int64_t e_fin = (NSUB == 1 && (rows_total + n_short * a.fin_rows) / n_ranges >= 2 * a.fin_rows) ? a.fin_rows : 0;
-  const int64_t virt = rows_total + n_short * e_fin;
-  int64_t pos = r * virt / n_ranges - e_fin * min(r, n_short);
-  const int64_t end = (r + 1) * virt / n_ranges - e_fin * min(r + 1, n_short);
-
-  const bool has_work = pos < end;
-  const int g0_first = has_work ? (int)(pos % G) : 0;
+  // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows} from the table the
+  // host built for this launch shape (abd_capi.hip: range_table) -- the 64-bit divisions that cut the plane into equal
+  // ranges cost ~700 scalar and ~80 vector instructions per wave when done here.  The first 16 ranges of every grid row
+  // (the workgroups that may carry a fused sum; one range per workgroup only: CB == 4) are fin_rows shorter, the
+  // others share the difference.  The split depends only on (grid.x, CB), never on the chains of the launch or on
+  // whether a sum is actually carried, so results are bit-identical either way.
+  const int r = blk * NSUB + sub;
+  const int4 rt = reinterpret_cast<const int4*>(a.range_tab)[r];
+  int lg = rt.x, g0 = rt.y, rows_left = rt.z;
+  const bool has_work = rows_left > 0;
+  const int g0_first = has_work ? g0 : 0;
 
   // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
   // that starts inside an individual's gaps reads them, and only entries up to its start gap.
@@ -208,12 +204,10 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const double2_t* tab_sw = tabs + (c * 2 + 1) * tstride;
   __syncthreads();
 
-  while (pos < end) {
+  for (; rows_left > 0; ++lg, g0 = 0) {
     // ---- one piece: lane group lg, gaps [g0, g1) ----
-    const int lg = (int)(pos / G);
-    const int g0 = (int)(pos - (int64_t)lg * G);
-    const int g1 = (int)min((int64_t)G, (int64_t)g0 + (end - pos));
-    pos += g1 - g0;
+    const int g1 = min(G, g0 + rows_left);
+    rows_left -= g1 - g0;
     // lanes past the last individual (only the last lane group has any) sit the piece out: EXEC masks them, so
     // they neither load nor contribute and the residuals need no 0/1 guard factor
     const int j = lg * 64 + lane;

@@ -86,6 +86,7 @@ struct EvalArgs {
   // packed indicator panels [nt][N]
   const uint64_t* vw;
   const uint64_t* pw;  // nullptr = ignore_pcrpos
+  const int32_t* range_tab;  // dense kernel: {first lane group, first gap, rows, 0} of every range of this launch shape
   const double* exp2_tab;  // dense kernel: 2^(j/1024), j = 0..1023, correctly rounded (copied to LDS per workgroup)
   double* partials;    // [n_chains][grid.x][ABD_NOUT]
   // dense kernel only: the fixed-order sum of the PREVIOUS launch's partials, done by the first
@@ -137,9 +138,28 @@ __device__ __forceinline__ void reduce16_step(double (&v)[16], int lane) {
     v[k] = keep + __shfl_xor(send, OFF, 64);
   }
 }
+// The same two first steps (lanes l <-> l ^ 32, then l <-> l ^ 16) with gfx950's v_permlane32_swap / v_permlane16_swap:
+// swap(a, b) leaves {a.lo, b.lo} / {a.hi, b.hi} in the two registers (halves of 32 lanes; for the 16-lane form the odd
+// rows of a and the even rows of b change places), so a + b IS the halving step -- 3 instructions per exchange of a
+// double instead of 2 ds_bpermute + 4 selects + 1 add, and the sums are the same bits (a + b = b + a).
+typedef unsigned int abd_u2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  abd_u2 lo, hi;
+  if (OFF == 32) {
+    lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  }
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
 __device__ __forceinline__ double wave_reduce16(double (&v)[16], int lane) {
-  reduce16_step<32, 8>(v, lane);
-  reduce16_step<16, 4>(v, lane);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = swap_add<32>(v[k], v[k + 8]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = swap_add<16>(v[k], v[k + 4]);
   reduce16_step<8, 2>(v, lane);
   reduce16_step<4, 1>(v, lane);
   double r = v[0];

@@ -334,6 +334,20 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.vw = c->vw;
   a.pw = c->ignore_pcr ? nullptr : c->pw;
   a.exp2_tab = c->exp2_tab;
+#ifdef ABD_STAMPS
+  {
+    static unsigned long long* stamps = nullptr;
+    if (!stamps) (void)hipHostMalloc((void**)&stamps, 4096 * 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    a.stamps = stamps;
+    if (const char* e = std::getenv("ABD_STAMPS_PTR_OUT")) {  // the probe reads the buffer through its address
+      FILE* f = std::fopen(e, "w");
+      if (f) {
+        std::fprintf(f, "%llu\n", (unsigned long long)(uintptr_t)stamps);
+        std::fclose(f);
+      }
+    }
+  }
+#endif
   a.G = c->G;
   a.N = c->N;
   a.nt = c->nt;

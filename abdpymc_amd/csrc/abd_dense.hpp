@@ -131,6 +131,18 @@ __device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, do
   }
 }
 
+#ifdef ABD_STAMPS
+// diagnostic build only (tools/probe_stamps.py): wave 0 of a few workgroups records s_memrealtime (100 MHz) at phase
+// boundaries into EvalArgs::stamps[blockIdx.x][16]; never compiled into the product
+#define ABD_STAMP(k)                                                                                  \
+  do {                                                                                                \
+    if (a.stamps && wave == 0 && lane == 0 && blockIdx.y == 0)                                        \
+      a.stamps[(int64_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                   \
+  } while (0)
+#else
+#define ABD_STAMP(k)
+#endif
+
 template <typename R, int CB, bool GRAD>
 __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
   // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction, 2^(j/1024) table
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   // eighth of the plane, so that the ~G/rows-per-range neighbouring ranges that re-read one lane group's packed
   // words (and the rows shared at range borders) find them in their own L2 instead of fetching them again.
   // blk = this workgroup's position in range order (a bijection of blockIdx.x for any grid size).
+  ABD_STAMP(0);
   const int nblk = (int)gridDim.x;
   const int xcd = (int)blockIdx.x % 8, q8 = nblk / 8, rem8 = nblk % 8;
   const int blk = a.xcd_remap ? xcd * q8 + min(xcd, rem8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const bool has_work = rows_left > 0;
   const int g0_first = has_work ? g0 : 0;
 
+  ABD_STAMP(1);
   // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
   // that starts inside an individual's gaps reads them, and only entries up to its start gap.
   const int n_entries = CB == ABD_WAVES_PER_BLOCK ? g0_first + 1 : tstride;
@@ -187,7 +201,9 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
   }
   if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, n_entries, lane);
+  ABD_STAMP(2);
   for (int e = tid; e < ABD_EXP2_TAB; e += ABD_BLOCK) tab_e2[e] = a.exp2_tab[e];
+  ABD_STAMP(3);
 
   double acc[16];
 #pragma unroll
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
   const double2_t* tab_sw = tabs + (c * 2 + 1) * tstride;
   __syncthreads();
+  ABD_STAMP(4);
 
   for (; rows_left > 0; ++lg, g0 = 0) {
     // ---- one piece: lane group lg, gaps [g0, g1) ----
@@ -226,6 +243,10 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     }
     const bool wj = p.waner[j] != 0;
     constrain_masks(Rw, P, a, I);
+#ifdef ABD_STAMPS
+    if (I[0] == 0x123456789abcdefull) acc[15] += 1.0;  // keeps the stamp behind the loads
+#endif
+    ABD_STAMP(5);
     if (g0 == 0) {  // each individual's gap 0 belongs to exactly one piece
       int n1 = 0;
 #pragma unroll
@@ -269,6 +290,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
       }
     }
 
+    ABD_STAMP(6);
     // ---- walk the piece: recurrence form (abd.py:288) + likelihood terms ----
     const double rho_j = wj ? rho_s : 1.0;  // abd.py:374
     double hd_s = 0.0;
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     }  // j < N
   }
 
+  ABD_STAMP(7);
   // ---- reduction: lanes -> wave -> block (LDS) -> per-block partial in global memory ----
   const double tot = wave_reduce16(acc, lane);
   if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
@@ -346,4 +369,5 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
     a.partials[((int64_t)(cbase + cc) * gridDim.x + blk) * ABD_NOUT + k] = v;  // rows in range order
   }
+  ABD_STAMP(8);
 }

@@ -86,6 +86,9 @@ struct EvalArgs {
   // packed indicator panels [nt][N]
   const uint64_t* vw;
   const uint64_t* pw;  // nullptr = ignore_pcrpos
+#ifdef ABD_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [grid.x][16] s_memrealtime at phase boundaries
+#endif
   const int32_t* range_tab;  // dense kernel: {first lane group, first gap, rows, 0} of every range of this launch shape
   const double* exp2_tab;  // dense kernel: 2^(j/1024), j = 0..1023, correctly rounded (copied to LDS per workgroup)
   double* partials;    // [n_chains][grid.x][ABD_NOUT]

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1657,14 +1658,27 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
     if (int rc = launch_tree(u)) return rc;
   }
+  // ABD_SAMPLER_PROFILE=1: how much of the wall time the host thread spends handling results and queueing launches
+  static const bool profile = std::getenv("ABD_SAMPLER_PROFILE") != nullptr;
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t_begin = clk::now();
+  clk::time_point t_handle;
+  double busy_s = 0.0;
+  long handled = 0;
   for (long spins = 0;;) {
     bool any = false, progressed = false;
     for (int u = 0; u < n_units; ++u) {
       Unit& un = units[(size_t)u];
       if (un.state == DONE) continue;
       any = true;
+      if (progressed && profile) {  // close the previous unit's handling interval
+        busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
+        t_handle = clk::now();
+      }
       if (!ready(u)) continue;
+      if (profile && !progressed) t_handle = clk::now();
       progressed = true;
+      ++handled;
       if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
       if (un.state == EVAL) {
         for (int q = 0; q < un.m; ++q)
@@ -1699,6 +1713,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         if (int rc = finish_iteration(u, true)) return rc;
       }
     }
+    if (progressed && profile) busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
     if (!any) break;
     if (progressed) {
       spins = 0;
@@ -1710,6 +1725,11 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     } else {
       __builtin_ia32_pause();
     }
+  }
+  if (profile) {
+    const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
+    std::fprintf(stderr, "abd sampler: %d units of %d chains, %ld results handled in %.3f s: host busy %.0f %% (%.2f us per result)\n",
+                 n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0);
   }
   // the context's stream continues behind everything the units queued
   for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;

@@ -143,6 +143,136 @@ __device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, do
 #define ABD_STAMP(k)
 #endif
 
+// The chain's constants as the gap loop wants them (wave-uniform; a VOP3 fma reads at most one scalar operand, so the
+// addends that meet another chain constant live in VGPRs, or every use costs a v_mov_b64).
+struct DenseChain {
+  double rho_n, temp_n, rho_s, init_n, init_s, perm_n, perm_s, d_n, d_s, c_n, c_s;
+};
+__device__ __forceinline__ DenseChain dense_chain(double perm_n, double temp_n, double rho_n, double init_n, double perm_s,
+                                                  double rho_s, double init_s, double b_n, double d_n, double b_s, double d_s) {
+  DenseChain k;
+  k.rho_n = rho_n;
+  k.temp_n = temp_n;
+  k.rho_s = rho_s;
+  k.init_n = to_vgpr(init_n);
+  k.init_s = to_vgpr(init_s);
+  k.perm_n = perm_n;
+  k.perm_s = perm_s;
+  k.d_n = d_n;
+  k.d_s = d_s;
+  k.c_n = b_n * (1.4426950408889634074 * ABD_EXP2_TAB);
+  k.c_s = b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
+  return k;
+}
+
+// State of one lane's individual at the end of gap g0 - 1 (g0 > 0): the dense design (abd.py:258-274) summed over the
+// exposures before the piece, rho^k from the chain's LDS tables (tab_s: the waning table or the table of ones).
+__device__ __forceinline__ void dense_start_state(const uint64_t (&I)[ABD_MAXT], const uint64_t (&V)[ABD_MAXT], int g0,
+                                                  const double2_t* tab_n, const double2_t* tab_s, double& tn, double& dn,
+                                                  double& ts, double& ds, uint32_t& cfn_hi, uint32_t& cfs_hi) {
+#pragma unroll
+  for (int t = 0; t < ABD_MAXT; ++t) {
+    if (t * 64 < g0) {
+      const int rel = g0 - t * 64;  // bits < rel of word t are before the piece
+      const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
+      uint64_t mi = I[t] & below, mv = V[t] & below;
+      if (mi != 0) cfn_hi = 0x3FF00000u;
+      if ((mi | mv) != 0) cfs_hi = 0x3FF00000u;
+      while (mi) {  // per-lane trip count
+        const int b = __builtin_ctzll(mi);
+        mi &= mi - 1;
+        const int idx = g0 - (t * 64 + b);  // = k + 1 with k = (g0 - 1) - r
+        const double2_t pn = tab_n[idx];
+        const double2_t ps = tab_s[idx];
+        tn += pn.x;
+        dn += pn.y;
+        ts += ps.x;
+        ds += ps.y;
+      }
+      while (mv) {
+        const int b = __builtin_ctzll(mv);
+        mv &= mv - 1;
+        const double2_t ps = tab_s[g0 - (t * 64 + b)];
+        ts += ps.x;
+        ds += ps.y;
+      }
+    }
+  }
+}
+
+// Walk gaps [g0, g1) of lane group lg: recurrence form (abd.py:288) + likelihood terms into acc.
+template <typename R, bool GRAD>
+__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const uint64_t (&I)[ABD_MAXT],
+                                           const uint64_t (&V)[ABD_MAXT], int lg, int lane, int g0, int g1, bool wj, double tn,
+                                           double dn, double ts, double ds, uint32_t cfn_hi, uint32_t cfs_hi,
+                                           const double* tab_e2, double (&acc)[16]) {
+  const int N = a.N;
+  const double rho_n = k.rho_n, temp_n = k.temp_n, init_n = k.init_n, init_s = k.init_s, perm_n = k.perm_n, perm_s = k.perm_s;
+  const double d_n = k.d_n, d_s = k.d_s, c_n = k.c_n, c_s = k.c_s;
+  const double rho_j = wj ? k.rho_s : 1.0;  // abd.py:374
+  double hd_s = 0.0;
+  const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
+  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // 34 rows of it fit 32 bits (abd_create checks)
+  const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
+  for (int gc = g0; gc < g1; gc += 32) {  // <= 32 gaps of indicator bits at a time
+    const int len = min(32, g1 - gc);
+    const uint32_t seg_i = extract_bits32(I, gc);
+    const uint32_t seg_v = extract_bits32(V, gc);
+    // gap rows through buffer loads: descriptor base = this chunk's first row of this lane group (scalar), scalar
+    // offset = row within the chunk, vector offset = the lane's constant -- no vector address arithmetic at all
+    const int64_t row0 = ((int64_t)gc * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.yx_n)) + row0, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.yx_s)) + row0, 0, -1, 0x00020000);
+    auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int gi) { return load_yx<R>(rs, lane_off, (uint32_t)gi * rstride); };
+
+    // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
+    auto step = [&](int gi, const YX<R>& on, const YX<R>& os) {
+      const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, (uint32_t)gi, 1u) & 0x3FF00000u;
+      const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, (uint32_t)gi, 1u) & 0x3FF00000u;
+      const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
+      cfn_hi |= ei_hi;
+      cfs_hi |= ei_hi | ev_hi;
+      dn = fma_s(rho_n, dn, tn);
+      tn = fma_s(rho_n, tn, e_i);
+      ds = fma_v(rho_j, ds, ts);
+      ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
+      const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
+      // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
+      const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
+      const double as = fma(cf_s, perm_s, init_s) + ts;
+      double h_n = 0.0, h_s = 0.0;
+      obs_pair_tab<GRAD>(an, (double)on.x, (double)on.y, c_n, d_n, as, (double)os.x, (double)os.y, c_s, d_s, tab_e2, acc,
+                         h_n, h_s);
+      if (GRAD) {
+        acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
+        acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
+        acc[A_N_HD] = fma(h_n, dn, acc[A_N_HD]);
+        acc[A_S_HC] = fma(h_s, cf_s, acc[A_S_HC]);
+        hd_s = fma(h_s, ds, hd_s);
+      }
+    };
+
+    // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
+    const int last = len - 1;
+    YX<R> n0 = ldrow(rs_n, 0), s0 = ldrow(rs_s, 0);
+    YX<R> n1 = ldrow(rs_n, min(1, last)), s1 = ldrow(rs_s, min(1, last));
+    int gi = 0;
+    for (; gi + 1 < len; gi += 2) {
+      const int ga = min(gi + 2, last), gb = min(gi + 3, last);
+      step(gi, n0, s0);
+      n0 = ldrow(rs_n, ga);
+      s0 = ldrow(rs_s, ga);
+      step(gi + 1, n1, s1);
+      n1 = ldrow(rs_n, gb);
+      s1 = ldrow(rs_s, gb);
+    }
+    if (gi < len) step(gi, n0, s0);
+  }
+  acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
+}
+
 template <typename R, int CB, bool GRAD>
 __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
   // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction, 2^(j/1024) table
@@ -209,13 +339,7 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.0;
 
-  const double rho_n = p.rho_n, temp_n = p.temp_n, rho_s = p.rho_s;
-  // a VOP3 fma reads at most one scalar operand: keep the addends that meet another chain constant in
-  // VGPRs, or every use costs a v_mov_b64
-  const double init_n = to_vgpr(p.init_n), init_s = to_vgpr(p.init_s);
-  const double perm_n = p.perm_n, perm_s = p.perm_s;
-  const double d_n = p.d_n, d_s = p.d_s;
-  const double c_n = p.b_n * (1.4426950408889634074 * ABD_EXP2_TAB), c_s = p.b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
+  const DenseChain kc = dense_chain(p.perm_n, p.temp_n, p.rho_n, p.init_n, p.perm_s, p.rho_s, p.init_s, p.b_n, p.d_n, p.b_s, p.d_s);
   const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
   const double2_t* tab_sw = tabs + (c * 2 + 1) * tstride;
   __syncthreads();
@@ -258,102 +382,10 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     // state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures
     double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
     uint32_t cfn_hi = 0, cfs_hi = 0;                 // exposure-so-far flags (abd.py:306): high word of 0.0 / 1.0
-    if (g0 > 0) {
-      const double2_t* tab_s = wj ? tab_sw : tab_ones;
-#pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
-        if (t * 64 < g0) {
-          const int rel = g0 - t * 64;  // bits < rel of word t are before the piece
-          const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
-          uint64_t mi = I[t] & below, mv = V[t] & below;
-          if (mi != 0) cfn_hi = 0x3FF00000u;
-          if ((mi | mv) != 0) cfs_hi = 0x3FF00000u;
-          while (mi) {  // per-lane trip count
-            const int b = __builtin_ctzll(mi);
-            mi &= mi - 1;
-            const int idx = g0 - (t * 64 + b);  // = k + 1 with k = (g0 - 1) - r
-            const double2_t pn = tab_n[idx];
-            const double2_t ps = tab_s[idx];
-            tn += pn.x;
-            dn += pn.y;
-            ts += ps.x;
-            ds += ps.y;
-          }
-          while (mv) {
-            const int b = __builtin_ctzll(mv);
-            mv &= mv - 1;
-            const double2_t ps = tab_s[g0 - (t * 64 + b)];
-            ts += ps.x;
-            ds += ps.y;
-          }
-        }
-      }
-    }
+    if (g0 > 0) dense_start_state(I, V, g0, tab_n, wj ? tab_sw : tab_ones, tn, dn, ts, ds, cfn_hi, cfs_hi);
 
     ABD_STAMP(6);
-    // ---- walk the piece: recurrence form (abd.py:288) + likelihood terms ----
-    const double rho_j = wj ? rho_s : 1.0;  // abd.py:374
-    double hd_s = 0.0;
-    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
-    const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // 34 rows of it fit 32 bits (abd_create checks)
-    const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
-    for (int gc = g0; gc < g1; gc += 32) {  // <= 32 gaps of indicator bits at a time
-      const int len = min(32, g1 - gc);
-      const uint32_t seg_i = extract_bits32(I, gc);
-      const uint32_t seg_v = extract_bits32(V, gc);
-      // gap rows through buffer loads: descriptor base = this chunk's first row of this lane group (scalar), scalar
-      // offset = row within the chunk, vector offset = the lane's constant -- no vector address arithmetic at all
-      const int64_t row0 = ((int64_t)gc * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
-      const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(a.yx_n)) + row0, 0, -1, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(a.yx_s)) + row0, 0, -1, 0x00020000);
-      auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int gi) { return load_yx<R>(rs, lane_off, (uint32_t)gi * rstride); };
-
-      // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
-      auto step = [&](int gi, const YX<R>& on, const YX<R>& os) {
-        const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, (uint32_t)gi, 1u) & 0x3FF00000u;
-        const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, (uint32_t)gi, 1u) & 0x3FF00000u;
-        const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
-        cfn_hi |= ei_hi;
-        cfs_hi |= ei_hi | ev_hi;
-        dn = fma_s(rho_n, dn, tn);
-        tn = fma_s(rho_n, tn, e_i);
-        ds = fma_v(rho_j, ds, ts);
-        ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
-        const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
-        // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
-        const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
-        const double as = fma(cf_s, perm_s, init_s) + ts;
-        double h_n = 0.0, h_s = 0.0;
-        obs_pair_tab<GRAD>(an, (double)on.x, (double)on.y, c_n, d_n, as, (double)os.x, (double)os.y, c_s, d_s, tab_e2, acc,
-                           h_n, h_s);
-        if (GRAD) {
-          acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
-          acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
-          acc[A_N_HD] = fma(h_n, dn, acc[A_N_HD]);
-          acc[A_S_HC] = fma(h_s, cf_s, acc[A_S_HC]);
-          hd_s = fma(h_s, ds, hd_s);
-        }
-      };
-
-      // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
-      const int last = len - 1;
-      YX<R> n0 = ldrow(rs_n, 0), s0 = ldrow(rs_s, 0);
-      YX<R> n1 = ldrow(rs_n, min(1, last)), s1 = ldrow(rs_s, min(1, last));
-      int gi = 0;
-      for (; gi + 1 < len; gi += 2) {
-        const int ga = min(gi + 2, last), gb = min(gi + 3, last);
-        step(gi, n0, s0);
-        n0 = ldrow(rs_n, ga);
-        s0 = ldrow(rs_s, ga);
-        step(gi + 1, n1, s1);
-        n1 = ldrow(rs_n, gb);
-        s1 = ldrow(rs_s, gb);
-      }
-      if (gi < len) step(gi, n0, s0);
-    }
-    acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
+    dense_walk<R, GRAD>(a, kc, I, V, lg, lane, g0, g1, wj, tn, dn, ts, ds, cfn_hi, cfs_hi, tab_e2, acc);
     }  // j < N
   }
 

@@ -122,6 +122,7 @@ SYMBOLS = {
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
     "abd_wait_fallbacks": (C.c_int64, [_P]),
+    "abd_resident_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "abd_is_dense": (C.c_int, [_P]),
 }
 
@@ -271,6 +272,13 @@ class Context:
     def wait_fallbacks(self) -> int:
         """Synchronous calls that had to fall back from the polled completion tag to a stream synchronise (expect 0)."""
         return int(self._lib.abd_wait_fallbacks(self._h))
+
+    @property
+    def resident_stats(self) -> dict:
+        """Resident evaluation kernels of the native sampler: launches, evaluations served, relaunches after a time-out."""
+        a, b, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(self._lib, self._lib.abd_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(r)))
+        return {"launches": a.value, "commands": b.value, "restarts": r.value}
 
     def algorithmic_bytes(self, n_chains: int) -> int:
         return int(self._lib.abd_algorithmic_bytes(self._h, n_chains))

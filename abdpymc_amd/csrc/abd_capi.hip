@@ -154,6 +154,7 @@ struct abd_ctx {
   double ev_total_ms = 0.0;
   int64_t ev_count = 0;
   int64_t wait_fallbacks = 0;  // synchronous calls whose completion tag never showed and that fell back to a stream synchronise
+  int64_t resident_launches = 0, resident_commands = 0, resident_restarts = 0;  // abd_resident_stats
   char name[256] = {0};
 };
 
@@ -1340,6 +1341,13 @@ int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t res
 }
 
 int64_t abd_wait_fallbacks(abd_ctx* c) { return c ? c->wait_fallbacks : -1; }
+int abd_resident_stats(abd_ctx* c, int64_t* launches, int64_t* commands, int64_t* restarts) {
+  if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
+  if (launches) *launches = c->resident_launches;
+  if (commands) *commands = c->resident_commands;
+  if (restarts) *restarts = c->resident_restarts;
+  return ABD_OK;
+}
 
 int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   if (!c) return 0;
@@ -1374,6 +1382,24 @@ struct abd_sampler {
   int8_t* d_rec_i8 = nullptr;   // [2][n][rec_chunk][G*N]  (i_raw, i) then [n][rec_chunk][N] (waner)
   std::vector<double> lp, gr;  // starting points' logp / gradient
   int unit = 1;                // chains per independent unit (sampler_run_units)
+  // dense cohorts, one chain per unit: the evaluation kernel stays resident for a whole trajectory (abd_resident.hpp)
+  struct Resident {
+    unsigned long long* mail_h = nullptr;  // mapped host memory: two mailboxes of ABD_RES_WORDS words, used alternately per launch
+    unsigned long long* mail_d = nullptr;  // ... as the device sees them
+    unsigned int* status_h = nullptr;      // behind the mailboxes: [0] how the kernel ended, [1] commands served
+    unsigned int* status_d = nullptr;
+    unsigned long long* relay = nullptr;   // device: ABD_RES_RELAY_WORDS words, then the `done` counter
+    double* partials = nullptr;            // device: [blocks][ABD_NOUT]
+    unsigned long long rounds = 0;         // commands served by this unit's kernels so far (done counter = rounds * blocks)
+    int cur = 0;
+    bool live = false;
+    int fails = 0;  // relaunches in a row without an answer
+  };
+  std::vector<Resident> res;
+  bool resident = false;
+  int res_blocks = 0;
+  size_t res_lds = 0;
+  unsigned long long res_cmd_timeout = 0, res_guard_timeout = 0;
 };
 
 namespace {
@@ -1391,6 +1417,203 @@ int accumulate_chain(abd_sampler* s, int k, hipStream_t st) {
   hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, st, a, (int8_t*)nullptr,
                      (double*)nullptr, (double*)nullptr, s->d_sums + (size_t)k * 3 * cells);
   HIP_TRY(hipGetLastError());
+  return ABD_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// ---- resident evaluation kernel of a sampler unit (abd_resident.hpp) ----
+
+size_t resident_lds_bytes(int G) {
+  return abd_res_tables_bytes(G) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
+         (size_t)ABD_EXP2_TAB * sizeof(double) + (size_t)ABD_RES_WORDS * sizeof(unsigned long long) +
+         (size_t)ABD_RES_PIECES * ABD_MAXT * ABD_BLOCK * sizeof(uint64_t) + 16;
+}
+
+template <typename R>
+hipError_t resident_occupancy(int* per_cu, size_t lds) {
+  const void* k = reinterpret_cast<const void*>(abd_dense_resident_kernel<R>);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, abd_dense_resident_kernel<R>, ABD_BLOCK, lds);
+}
+
+void resident_free(abd_sampler* s) {
+  for (auto& r : s->res) {
+    if (r.mail_h) (void)hipHostFree(r.mail_h);
+    if (r.relay) (void)hipFree(r.relay);
+    if (r.partials) (void)hipFree(r.partials);
+    r = abd_sampler::Resident();
+  }
+  s->res.clear();
+  s->resident = false;
+}
+
+// Decide whether the units of this sampler keep their evaluation kernel resident, and allocate what that needs.
+// Needs: a dense cohort, one chain per unit, every range of the unit's launch shape made of at most two pieces, and
+// room on the chip for ALL units' workgroups at once (a resident workgroup that cannot start would be waited for).
+int resident_setup(abd_sampler* s) {
+  abd_ctx* c = s->c;
+  s->resident = false;
+  // Opt-in (ABD_RESIDENT=1): measured at config 3, trajectories without the sweep run 10-25 % faster,
+  // but with the sweep the iteration gets SLOWER (2.2 -> 2.8 ms with 4 chains): a sweep workgroup (768 threads, 115 KB
+  // of LDS) does not fit on a CU next to the other chains' resident workgroups, so every sweep waits for all the other
+  // trajectories to end.
+  const char* e = std::getenv("ABD_RESIDENT");
+  if (!e || std::atoi(e) == 0) return ABD_OK;
+  if (!c->dense || s->unit != 1) return ABD_OK;
+  const int n_units = s->n;
+  const int blocks = dense_blocks(c, 1, 2, 1);
+  const size_t lds = resident_lds_bytes(c->G);
+  int per_cu = 0;
+  hipError_t oe = c->storage == ABD_STORE_F32 ? resident_occupancy<float>(&per_cu, lds) : resident_occupancy<double>(&per_cu, lds);
+  if (oe != hipSuccess) return fail(ABD_ERR_HIP, "resident kernel occupancy: %s", hipGetErrorString(oe));
+  if ((int64_t)n_units * blocks > (int64_t)per_cu * c->n_cu) return ABD_OK;
+  if (n_units > 4 && !(e && std::atoi(e) >= 2)) return ABD_OK;  // more concurrent kernels than hardware queues (ABD_RESIDENT=2 tries anyway)
+  const int32_t* tab = nullptr;
+  if (int rrc = range_table(c, blocks, ABD_WAVES_PER_BLOCK, &tab)) return rrc;
+  {  // at most two pieces per range: rows <= (G - first gap) + G
+    std::vector<int32_t> h((size_t)blocks * ABD_WAVES_PER_BLOCK * 4);
+    HIP_TRY(hipMemcpy(h.data(), tab, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < h.size() / 4; ++r)
+      if (h[r * 4 + 2] > (c->G - h[r * 4 + 1]) + c->G) return ABD_OK;
+  }
+  s->res.resize((size_t)n_units);
+  for (auto& r : s->res) {
+    const size_t mail_bytes = 2 * ABD_RES_WORDS * sizeof(unsigned long long) + 128;
+    HIP_TRY(hipHostMalloc((void**)&r.mail_h, mail_bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(r.mail_h, 0, mail_bytes);
+    HIP_TRY(hipHostGetDevicePointer((void**)&r.mail_d, r.mail_h, 0));
+    r.status_h = reinterpret_cast<unsigned int*>(r.mail_h + 2 * ABD_RES_WORDS);
+    r.status_d = reinterpret_cast<unsigned int*>(r.mail_d + 2 * ABD_RES_WORDS);
+    const size_t relay_bytes = (size_t)(ABD_RES_RELAY_WORDS + 16) * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc(&r.relay, relay_bytes));
+    HIP_TRY(hipMemset(r.relay, 0, relay_bytes));
+    HIP_TRY(hipMalloc(&r.partials, (size_t)blocks * ABD_NOUT * sizeof(double)));
+  }
+  s->res_blocks = blocks;
+  s->res_lds = lds;
+  double ms = 20.0;  // without a command for this long the kernel leaves by itself (the host relaunches it)
+  if (const char* t = std::getenv("ABD_RESIDENT_TIMEOUT_MS")) ms = std::max(0.001, std::atof(t));
+  s->res_cmd_timeout = (unsigned long long)(ms * 1e5);  // s_memrealtime: 100 MHz
+  s->res_guard_timeout = s->res_cmd_timeout * 10ull + 10000000ull;
+  s->resident = true;
+  return ABD_OK;
+}
+
+// the command: chain constants of theta, sequence number last in each 64-byte line (x86 stores become visible in order)
+void resident_write(abd_sampler::Resident& r, const ChainPar& cp, double seq) {
+  volatile unsigned long long* m = r.mail_h + (size_t)r.cur * ABD_RES_WORDS;
+  const double lineA[7] = {cp.perm_n, cp.temp_n, cp.rho_n, cp.init_n, cp.perm_s, cp.rho_s, cp.init_s};
+  const double lineB[4] = {cp.b_n, cp.d_n, cp.b_s, cp.d_s};
+  unsigned long long w, sq;
+  std::memcpy(&sq, &seq, sizeof sq);
+  for (int k = 0; k < 7; ++k) {
+    std::memcpy(&w, &lineA[k], sizeof w);
+    m[k] = w;
+  }
+  __atomic_store_n(const_cast<unsigned long long*>(m) + 7, sq, __ATOMIC_RELEASE);
+  for (int k = 0; k < 4; ++k) {
+    std::memcpy(&w, &lineB[k], sizeof w);
+    m[8 + k] = w;
+  }
+  __atomic_store_n(const_cast<unsigned long long*>(m) + 15, sq, __ATOMIC_RELEASE);
+}
+
+// Evaluate chain `chain` at theta through unit u's resident kernel (launched here if it is not running); the result
+// lands in row 0 of slot kSyncSlot + u under the tag c->seq, like a launched evaluation's.
+int resident_eval(abd_sampler* s, int u, int32_t chain, const double* theta) {
+  abd_ctx* c = s->c;
+  abd_sampler::Resident& r = s->res[(size_t)u];
+  const int slot = kSyncSlot + u;
+  ResultSlot& rs = c->results[slot];
+  rs.n = 1;
+  rs.grad = true;
+  rs.chains.assign(1, chain);
+  rs.theta.assign(theta, theta + ABD_N_THETA);
+  const ChainPar cp = chain_par(c, chain, theta);
+  if (r.live) {
+    c->seq += 1.0;
+    r.rounds += 1;
+    c->resident_commands++;
+    resident_write(r, cp, c->seq);
+    return ABD_OK;
+  }
+  const int pi = u % c->n_streams;
+  abd_ctx::Pipe& pp = c->pipe[pi];
+  if (int frc = flush_pipe(c, pi)) return frc;
+  if (pi > 0) pp.busy = true;
+  ResidentArgs ra;
+  base_args(c, ra.a);
+  ra.a.n_chains = 1;
+  ra.a.ch[0] = cp;
+  if (int rrc = range_table(c, s->res_blocks, ABD_WAVES_PER_BLOCK, &ra.a.range_tab)) return rrc;
+  ra.a.partials = r.partials;
+  ra.a.fin_rows = c->fin_rows;
+  ra.a.xcd_remap = c->xcd_remap ? 1 : 0;
+  ra.mail = r.mail_d + (size_t)r.cur * ABD_RES_WORDS;
+  ra.relay = r.relay;
+  ra.done = r.relay + ABD_RES_RELAY_WORDS;
+  ra.done0 = r.rounds * (unsigned long long)s->res_blocks;
+  ra.out = c->d_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  ra.status = r.status_d;
+  c->seq += 1.0;  // whatever an earlier kernel of this unit left in the relay words is older than this
+  ra.seq0 = c->seq;
+  ra.cmd_timeout = s->res_cmd_timeout;
+  ra.poll_naps = 1;
+  if (const char* e = std::getenv("ABD_RES_POLL_NAPS")) ra.poll_naps = std::max(0, std::atoi(e));
+#ifdef ABD_STAMPS
+  ra.dbg_launch = (int)c->resident_launches;
+  ra.dbg_unit = u;
+#endif
+  ra.guard_timeout = s->res_guard_timeout;
+  r.status_h[0] = 0;
+  r.status_h[1] = 0;
+  c->seq += 1.0;
+  r.rounds += 1;
+  resident_write(r, cp, c->seq);  // the first command is there before the kernel starts
+  if (c->storage == ABD_STORE_F32)
+    hipLaunchKernelGGL(abd_dense_resident_kernel<float>, dim3(s->res_blocks), dim3(ABD_BLOCK), s->res_lds, pp.st, ra);
+  else
+    hipLaunchKernelGGL(abd_dense_resident_kernel<double>, dim3(s->res_blocks), dim3(ABD_BLOCK), s->res_lds, pp.st, ra);
+  HIP_TRY(hipGetLastError());
+  r.live = true;
+  c->resident_launches++;
+  c->resident_commands++;
+  return ABD_OK;
+}
+
+// end of the trajectory: the kernel leaves (the next launch of this unit uses the other mailbox, so a kernel that is
+// still on its way out never sees a command that is not meant for it)
+void resident_quit(abd_sampler* s, int u) {
+  abd_ctx* c = s->c;
+  abd_sampler::Resident& r = s->res[(size_t)u];
+  if (!r.live) return;
+  c->seq += 1.0;
+  volatile unsigned long long* m = r.mail_h + (size_t)r.cur * ABD_RES_WORDS;
+  const double q = c->seq + 0.5;
+  unsigned long long sq;
+  std::memcpy(&sq, &q, sizeof sq);
+  __atomic_store_n(const_cast<unsigned long long*>(m) + 7, sq, __ATOMIC_RELEASE);
+  __atomic_store_n(const_cast<unsigned long long*>(m) + 15, sq, __ATOMIC_RELEASE);
+  r.cur ^= 1;
+  r.live = false;
+}
+
+// the kernel of unit u left on its own (no command for cmd_timeout): start over from a clean counter
+int resident_recover(abd_sampler* s, int u) {
+  abd_ctx* c = s->c;
+  abd_sampler::Resident& r = s->res[(size_t)u];
+  HIP_TRY(hipStreamSynchronize(c->pipe[u % c->n_streams].st));
+  HIP_TRY(hipMemset(r.relay + ABD_RES_RELAY_WORDS, 0, sizeof(unsigned long long)));
+  r.rounds = 0;
+  r.cur ^= 1;
+  r.live = false;
+  c->resident_restarts++;
   return ABD_OK;
 }
 
@@ -1435,6 +1658,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   if (const char* e = std::getenv("ABD_GROUP_BLOCKS_PER_CU")) c->group_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
   // the starting points through the launch shape the units will use
   rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
+  if (!rc) rc = resident_setup(s);
   for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
     const int m = std::min(s->unit, n - lo);
     rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, u % c->n_streams);
@@ -1442,11 +1666,13 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     if (!rc) rc = fetch_slot(c, kSyncSlot + u, s->lp.data() + lo, s->gr.data() + (size_t)lo * ABD_N_THETA);
   }
   if (rc) {
+    resident_free(s);
     delete s;
     return rc;
   }
   for (int k = 0; k < n; ++k) {
     if (!std::isfinite(s->lp[(size_t)k])) {
+      resident_free(s);
       delete s;
       return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
     }
@@ -1460,6 +1686,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     if (e == hipSuccess) e = hipMemsetAsync(s->d_sums, 0, bytes, c->stream);
     if (e != hipSuccess) {
       if (s->d_sums) (void)hipFree(s->d_sums);
+      resident_free(s);
       delete s;
       return fail(ABD_ERR_HIP, "sampler sums: %s", hipGetErrorString(e));
     }
@@ -1470,6 +1697,11 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
 
 void abd_sampler_destroy(abd_sampler* s) {
   if (!s) return;
+  if (!s->res.empty()) {
+    (void)hipSetDevice(s->c->device);
+    (void)hipDeviceSynchronize();
+    resident_free(s);
+  }
   if (s->d_sums || s->d_rec_mu || s->d_rec_i8) {
     (void)hipSetDevice(s->c->device);
     (void)hipStreamSynchronize(s->c->stream);
@@ -1585,8 +1817,19 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
       std::memcpy(un.th.data() + (size_t)un.m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
       ++un.m;
     }
-    return un.m ? launch_eval(u) : ABD_OK;
+    if (!un.m) return ABD_OK;
+    if (!s->resident) return launch_eval(u);
+    // one chain per unit: its evaluation kernel stays on the device until the tree stops (abd_resident.hpp)
+    if (int rc = resident_eval(s, u, un.ids[0], un.th.data())) return rc;
+    un.tag = c->seq;
+    return ABD_OK;
   };
+  struct QuitGuard {  // whichever way this function is left, no resident kernel keeps waiting for commands
+    abd_sampler* s;
+    ~QuitGuard() {
+      for (size_t u = 0; u < s->res.size(); ++u) resident_quit(s, (int)u);
+    }
+  } quit_guard{s};
   auto ready = [&](int u) -> bool {  // have all result rows of the unit's launch landed? (never blocks)
     const Unit& un = units[(size_t)u];
     volatile const double* rows = c->h_out + (size_t)(kSyncSlot + u) * c->n_slots * ABD_NOUT;
@@ -1675,16 +1918,30 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
         t_handle = clk::now();
       }
-      if (!ready(u)) continue;
+      if (!ready(u)) {
+        if (!(s->resident && s->res[(size_t)u].live && *(volatile unsigned int*)s->res[(size_t)u].status_h == 2u)) continue;
+        // the kernel gave up waiting (the host was away for longer than its time-out).  Once it has left for good, either
+        // the answer has landed after all (it may leave while the last workgroup is still summing) or the command was
+        // never seen: relaunch and ask again
+        if (int rc = resident_recover(s, u)) return rc;
+        if (!ready(u)) {
+          if (++s->res[(size_t)u].fails > 50) return fail(ABD_ERR_STATE, "the resident evaluation kernel of chain %d does not answer", un.ids[0]);
+          if (int rc = resident_eval(s, u, un.ids[0], un.th.data())) return rc;
+          un.tag = c->seq;
+          continue;
+        }
+      }
       if (profile && !progressed) t_handle = clk::now();
       progressed = true;
       ++handled;
+      if (s->resident) s->res[(size_t)u].fails = 0;
       if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
       if (un.state == EVAL) {
         for (int q = 0; q < un.m; ++q)
           s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
         if (int rc = launch_tree(u)) return rc;
         if (un.m) continue;  // some tree of the unit is still growing
+        if (s->resident) resident_quit(s, u);
         for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
         if (!s->o.gibbs) {
           if (int rc = finish_iteration(u, false)) return rc;

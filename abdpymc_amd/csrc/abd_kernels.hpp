@@ -440,6 +440,7 @@ __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int
 }
 
 #include "abd_dense.hpp"
+#include "abd_resident.hpp"
 
 // ================================================================================================
 // Sparse-list kernel (the real cohorts: several dilutions per serum sample, most cells empty)

@@ -248,6 +248,11 @@ int abd_kernel_timing(abd_ctx* ctx, int32_t mode);
  * show within ~2 M polls the call falls back to a stream synchronise (still correct).  Number of such fall-backs
  * since abd_create: anything but 0 means the tag path has regressed. */
 int64_t abd_wait_fallbacks(abd_ctx* ctx);
+/* The native sampler keeps the evaluation kernel of a dense cohort's chain resident on the device for a whole NUTS
+ * trajectory and feeds it commands through mapped host memory (see abd_sampler_create).  Since abd_create: kernels
+ * launched, evaluations they served, and relaunches after a kernel left on its own because the host did not send a
+ * command within its time-out (harmless, but expected to stay 0 on an idle machine).  Any pointer may be NULL. */
+int abd_resident_stats(abd_ctx* ctx, int64_t* launches, int64_t* commands, int64_t* restarts);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* Tuning hook (benchmarks / experiments): number of 256-thread workgroups of the evaluation grid

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Full-size Gibbs sweeps (config 3: 10 000 x 200, 4 chains) for timing / rocprofv3 counter passes."""
+"""Full-size Gibbs sweeps (config 3: 10 000 x 200, 4 chains) for timing / rocprofv3 counter passes.
+usage: probe_gibbs.py [reps] [truth|random] [chains]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +8,8 @@ sys.path.insert(0, ROOT)
 from abdpymc_amd import synthetic
 from abdpymc_amd._native import Context
 
-N, G, C = 10000, 200, 4
+N, G = 10000, 200
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 sc = synthetic.make_cohort(N, G)
 ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C)
@@ -24,4 +26,4 @@ ctx.gibbs_sweep(np.arange(C), th, seed=1, sweep=0)
 t0 = time.perf_counter()
 for s in range(reps):
     ctx.gibbs_sweep(np.arange(C), th, seed=1, sweep=1 + s)
-print(f"sweep {1e3 * (time.perf_counter() - t0) / reps:.2f} ms")
+print(f"{C} chains: sweep {1e3 * (time.perf_counter() - t0) / reps:.2f} ms")

@@ -34,12 +34,15 @@ else:
     th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
 for c in range(C):
     ctx.set_discrete(c, *states[c])
-smp = ctx.sampler(np.arange(C), th0, tune=10 ** 6, seed=3, gibbs=False)
-smp.run(15)  # step size settles
+ta = float(os.environ.get("ABD_PROBE_TARGET_ACCEPT", "0.8"))  # closer to 1: smaller steps, longer trees
+gibbs = os.environ.get("ABD_PROBE_GIBBS", "0") == "1"  # 1: the compound step (sweep after every transition)
+smp = ctx.sampler(np.arange(C), th0, tune=10 ** 6, seed=3, gibbs=gibbs, target_accept=ta)
+smp.run(60 if gibbs else 15)  # step size settles (and, with the sweep, the discrete state leaves its random start)
 t0 = time.perf_counter()
 _, st = smp.run(iters)
 dt = time.perf_counter() - t0
 evals = float(st["n_steps"].sum())
 print(f"{cfg} chains={C} unit={os.environ.get('ABD_SAMPLER_UNIT', 'auto')}: {evals / dt:,.0f} evals/s as seen by NUTS "
-      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains)")
+      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains, "
+      f"{dt / (evals / C) * 1e6:.1f} us per leapfrog of a chain); resident kernels: {ctx.resident_stats}")
 smp.close()

@@ -127,6 +127,12 @@ struct abd_ctx {
   hipEvent_t join_ev[kMaxPipes] = {};
   double seq = 0.0;  // completion tags: 1, 2, 3, ... (exact in a double)
   bool fuse_finalize = true;
+  // ABD_OBS_FUSED_SUM=1: the observation-lane kernel sums its own partial rows (last workgroup in) instead of a second
+  // launch.  Off by default: it halves the host's time per evaluation (8.1 -> 4.5 us) but the hand-off inside the kernel
+  // (write-through rows, one atomic round trip, coherent re-read) costs 4.4 us more than the queued second launch, and
+  // the best rate the native sampler reaches on the reference's cohorts does not move
+  bool obs_fused = false;
+  unsigned int* d_fin_count = nullptr;  // [kMaxPipes][ABD_MAX_BATCH] zeroed counters of that sum
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;
@@ -392,8 +398,7 @@ hipError_t launch_sparse_g(bool grad, dim3 grid, size_t lds, hipStream_t st, con
 }
 template <typename R>
 hipError_t launch_sparse(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  switch (C) {
-    case 4: return launch_sparse_g<R, 4>(grad, grid, lds, st, a);
+  switch (C) {  // no 4-chain form: it needs 169 VGPRs (2 waves per SIMD) and spills 245 SGPRs (pick_cpw caps this path at 2)
     case 2: return launch_sparse_g<R, 2>(grad, grid, lds, st, a);
     default: return launch_sparse_g<R, 1>(grad, grid, lds, st, a);
   }
@@ -501,14 +506,15 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   a.n_chains = n;
   for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
   const bool lanes = !c->dense && c->obs_lanes;
-  const int cpw = lanes ? 1 : pick_cpw(c, n);
+  int cpw = lanes ? 1 : pick_cpw(c, n);
+  if (!lanes && !c->dense) cpw = std::min(cpw, 2);  // wave-per-individual list kernel: see launch_sparse
   // stream-ordered dense launches rotate over the pipes; everything else runs on pipe 0 after a join
   const bool rotate = deferred && c->n_pipes > 1 && c->dense && c->fuse_finalize && c->timing != 1;  // timing 1: one launch at a time
   int blocks;
   size_t lds;
   if (lanes) {
     blocks = c->ob_n + c->ob_s + c->ob_c;
-    lds = (size_t)2 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double);
+    lds = abd_obs_lds_head(c->G) + (c->obs_fused ? (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double) : 0);
   } else if (c->dense) {
     blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate ? 1 : 0), n / cpw);
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK, true);
@@ -534,6 +540,12 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   const int buf = pp.pbuf;
   pp.pbuf ^= 1;
   a.partials = pp.partials[buf];
+  const bool fused_sum = lanes && c->obs_fused;  // the kernel sums its own partial rows (abd_obs.hpp): no second launch
+  if (fused_sum) {
+    a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
+    a.fin_out = d_out_rows;
+    a.fin_tag = c->seq + 1.0;
+  }
   a.fin_rows = c->fin_rows;
   a.xcd_remap = c->xcd_remap ? 1 : 0;
   if (c->dense && c->fuse_finalize && pp.on && pp.n <= blocks) {
@@ -577,12 +589,13 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
                                      : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);
   if (c->timing == 1) HIP_TRY(hipEventRecord(e1, pp.st));
   HIP_TRY(le);
+  c->seq += 1.0;
+  if (fused_sum) return ABD_OK;
   pp.on = true;
   pp.buf = buf;
   pp.n = n;
   pp.blocks = blocks;
   pp.out = d_out_rows;
-  c->seq += 1.0;
   pp.tag = c->seq;
   if (!(c->dense && c->fuse_finalize)) return flush_pipe(c, pi);
   return ABD_OK;
@@ -804,6 +817,7 @@ void free_ctx(abd_ctx* c) {
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_work) (void)hipFree(c->d_work);
   if (c->d_counts_chain) (void)hipFree(c->d_counts_chain);
+  if (c->d_fin_count) (void)hipFree(c->d_fin_count);
   if (c->h_counts_chain) (void)hipHostFree(c->h_counts_chain);
   if (c->d_det) (void)hipFree(c->d_det);
   for (auto& e : c->ev_pool) {
@@ -991,6 +1005,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
   CREATE_TRY(hipMalloc(&c->d_work, (size_t)2 * c->n_slots * sizeof(unsigned int)));
   CREATE_TRY(hipMalloc(&c->d_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
+  CREATE_TRY(hipMalloc(&c->d_fin_count, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
+  CREATE_TRY(hipMemset(c->d_fin_count, 0, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
+  if (const char* e = std::getenv("ABD_OBS_FUSED_SUM")) c->obs_fused = std::atoi(e) != 0;
   CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
   c->results.resize((size_t)kResultSlots + c->n_sync_slots);
@@ -1906,7 +1923,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   using clk = std::chrono::steady_clock;
   const clk::time_point t_begin = clk::now();
   clk::time_point t_handle;
-  double busy_s = 0.0;
+  double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0;
   long handled = 0;
   for (long spins = 0;;) {
     bool any = false, progressed = false;
@@ -1935,11 +1952,25 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
       progressed = true;
       ++handled;
       if (s->resident) s->res[(size_t)u].fails = 0;
+      clk::time_point tp0;
+      if (profile) tp0 = clk::now();
       if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
+      if (profile) {
+        const clk::time_point t1 = clk::now();
+        prof_fetch += std::chrono::duration<double>(t1 - tp0).count();
+        tp0 = t1;
+      }
       if (un.state == EVAL) {
         for (int q = 0; q < un.m; ++q)
           s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
-        if (int rc = launch_tree(u)) return rc;
+        if (profile) {
+          const clk::time_point t1 = clk::now();
+          prof_feed += std::chrono::duration<double>(t1 - tp0).count();
+          tp0 = t1;
+        }
+        const int lrc = launch_tree(u);
+        if (profile) prof_launch += std::chrono::duration<double>(clk::now() - tp0).count();
+        if (lrc) return lrc;
         if (un.m) continue;  // some tree of the unit is still growing
         if (s->resident) resident_quit(s, u);
         for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
@@ -1985,8 +2016,11 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   }
   if (profile) {
     const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
-    std::fprintf(stderr, "abd sampler: %d units of %d chains, %ld results handled in %.3f s: host busy %.0f %% (%.2f us per result)\n",
-                 n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0);
+    std::fprintf(stderr, "abd sampler: %d units of %d chains, %ld results handled in %.3f s: host busy %.0f %% (%.2f us per result: "
+                 "%.2f assemble, %.2f NUTS, %.2f queueing the next evaluation)\n",
+                 n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
+                 handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
+                 handled ? 1e6 * prof_launch / handled : 0.0);
   }
   // the context's stream continues behind everything the units queued
   for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;

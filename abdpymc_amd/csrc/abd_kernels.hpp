@@ -101,6 +101,11 @@ struct EvalArgs {
   int32_t fin_rows;    // gap rows the finalizing workgroups are excused from
   int32_t xcd_remap;   // dense kernel: workgroup -> range mapping that keeps neighbouring ranges on one XCD
   double prev_tag;          // completion tag of the previous launch (see finalize_chain)
+  // observation-lane kernel: the workgroup of a chain that finishes last sums that chain's partial rows itself
+  // (abd_obs.hpp) -- one launch per evaluation instead of two.  fin_count: one zeroed counter per grid row.
+  unsigned int* fin_count;
+  double* fin_out;
+  double fin_tag;
   int32_t G, N, nt, n_chunks;
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
   uint64_t chunk_mask[3][ABD_MAXT];
@@ -432,6 +437,42 @@ __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int
   if (tid == 0) {
     // one lane writes the row, then -- behind a system-scope fence -- the launch's tag into the spare 16th
     // double: a host that polls the tag in mapped memory sees a complete row without a stream synchronise
+#pragma unroll
+    for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];
+    __threadfence_system();
+    __hip_atomic_store(out + (ABD_NOUT - 1), tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// finalize_chain with device-coherent loads of the partial rows (they were written write-through by other workgroups of the
+// SAME kernel, possibly on other XCDs: a plain load could hit a stale line of this XCD's L2).  Same order of additions, same bits.
+template <int NT>
+__device__ __forceinline__ void finalize_chain_coherent(const double* p, int n_blocks, double* out, double* sm, int tid, double tag) {
+  const int k = tid % ABD_NOUT;
+  for (int part = tid / ABD_NOUT; part < ABD_FIN_PARTS; part += NT / ABD_NOUT) {
+    double v = 0.0;
+    for (int b0 = part; b0 < n_blocks; b0 += 16 * ABD_FIN_PARTS) {
+      double q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * ABD_FIN_PARTS;
+        q[u] = b < n_blocks ? __hip_atomic_load(p + (int64_t)b * ABD_NOUT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += q[u];
+    }
+    sm[part * ABD_NOUT + k] = v;
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (tid < ABD_NOUT) {
+#pragma unroll
+    for (int q = 0; q < ABD_FIN_PARTS; ++q) t += sm[q * ABD_NOUT + tid];
+  }
+  __syncthreads();
+  if (tid < ABD_NOUT) sm[tid] = t;
+  __syncthreads();
+  if (tid == 0) {
 #pragma unroll
     for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];
     __threadfence_system();

@@ -68,42 +68,6 @@ __device__ __forceinline__ double res_uniform(double v) {
 }
 __device__ __forceinline__ bool res_is_eval(double seq) { return seq == __builtin_floor(seq); }
 
-// finalize_chain with device-coherent loads of the partial rows (they were written write-through by other XCDs during
-// this kernel: a plain load could hit a stale line of this XCD's L2).  Same order of additions, same bits.
-template <int NT>
-__device__ __forceinline__ void finalize_chain_coherent(const double* p, int n_blocks, double* out, double* sm, int tid, double tag) {
-  const int k = tid % ABD_NOUT;
-  for (int part = tid / ABD_NOUT; part < ABD_FIN_PARTS; part += NT / ABD_NOUT) {
-    double v = 0.0;
-    for (int b0 = part; b0 < n_blocks; b0 += 16 * ABD_FIN_PARTS) {
-      double q[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int b = b0 + u * ABD_FIN_PARTS;
-        q[u] = b < n_blocks ? __hip_atomic_load(p + (int64_t)b * ABD_NOUT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v += q[u];
-    }
-    sm[part * ABD_NOUT + k] = v;
-  }
-  __syncthreads();
-  double t = 0.0;
-  if (tid < ABD_NOUT) {
-#pragma unroll
-    for (int q = 0; q < ABD_FIN_PARTS; ++q) t += sm[q * ABD_NOUT + tid];
-  }
-  __syncthreads();
-  if (tid < ABD_NOUT) sm[tid] = t;
-  __syncthreads();
-  if (tid == 0) {
-#pragma unroll
-    for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];
-    __threadfence_system();
-    __hip_atomic_store(out + (ABD_NOUT - 1), tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 #ifdef ABD_STAMPS
 // diagnostic build (tools/probe_resident_phases.py): thread 0 of every workgroup adds up, over the commands it serves,
 // the ticks of s_memrealtime it spends in each phase of a round and leaves the sums in EvalArgs::stamps[blockIdx.x][16]

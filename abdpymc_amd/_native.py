@@ -123,6 +123,7 @@ SYMBOLS = {
     "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
     "abd_wait_fallbacks": (C.c_int64, [_P]),
     "abd_resident_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "abd_stream_queues": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "abd_is_dense": (C.c_int, [_P]),
 }
 
@@ -279,6 +280,12 @@ class Context:
         a, b, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _check(self._lib, self._lib.abd_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(r)))
         return {"launches": a.value, "commands": b.value, "restarts": r.value}
+
+    def stream_queues(self):
+        """Hardware queue of each of the context's 8 HIP streams (streams with the same number serialise their kernels)."""
+        q = (C.c_int32 * 8)()
+        _check(self._lib, self._lib.abd_stream_queues(self._h, q, 8))
+        return list(q)
 
     def algorithmic_bytes(self, n_chains: int) -> int:
         return int(self._lib.abd_algorithmic_bytes(self._h, n_chains))

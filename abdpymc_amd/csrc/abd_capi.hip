@@ -159,6 +159,9 @@ struct abd_ctx {
   size_t ev_used = 0;
   double ev_total_ms = 0.0;
   int64_t ev_count = 0;
+  int queue_of_pipe[kMaxPipes] = {};  // probe_stream_queues: streams with the same number share a hardware queue
+  int n_queues = 0;                   // 0 = not probed yet
+  int pipe_order[kMaxPipes] = {0, 1, 2, 3, 4, 5, 6, 7};  // one stream of every hardware queue first (probe_stream_queues)
   int64_t wait_fallbacks = 0;  // synchronous calls whose completion tag never showed and that fell back to a stream synchronise
   int64_t resident_launches = 0, resident_commands = 0, resident_restarts = 0;  // abd_resident_stats
   char name[256] = {0};
@@ -465,6 +468,58 @@ int range_table(abd_ctx* c, int blocks, int nsub, const int32_t** out) {
   *out = rt.dev;
   return ABD_OK;
 }
+
+// Which of the context's streams can have kernels on the device at the same time?  HIP multiplexes its streams over a few
+// hardware queues (4 by default) and a queue runs one kernel after the other, whichever stream it came from.  One wave
+// per stream that stays for 150 us, launched back to back: a stream whose wave starts only when an earlier stream's
+// wave has ended shares that stream's queue.  ~0.5 ms, once per context.
+int probe_stream_queues(abd_ctx* c) {
+  if (c->n_queues > 0) return ABD_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, (size_t)kMaxPipes * 2 * sizeof(unsigned long long)));
+  const unsigned long long ticks = 15000;  // 150 us
+  for (int pi = 0; pi < c->n_streams; ++pi) hipLaunchKernelGGL(abd_spin_kernel, dim3(1), dim3(64), 0, c->pipe[pi].st, d + 2 * pi, ticks);
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess) le = hipDeviceSynchronize();
+  unsigned long long h[kMaxPipes * 2] = {};
+  if (le == hipSuccess) le = hipMemcpy(h, d, sizeof(unsigned long long) * 2 * (size_t)c->n_streams, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(le);
+  int nq = 0;
+  for (int j = 0; j < c->n_streams; ++j) {
+    int q = -1;
+    for (int i = 0; i < j && q < 0; ++i)
+      if (h[2 * j] + ticks / 10 >= h[2 * i + 1] && c->queue_of_pipe[i] >= 0) {
+        // started (about) when stream i's wave ended or later: behind it in the same queue -- unless another stream
+        // of that queue explains it just as well, which is the same answer
+        bool overlaps_all_of_queue = false;
+        for (int k = 0; k < j; ++k)
+          if (c->queue_of_pipe[k] == c->queue_of_pipe[i] && h[2 * j] + ticks / 10 < h[2 * k + 1]) overlaps_all_of_queue = true;
+        if (!overlaps_all_of_queue) q = c->queue_of_pipe[i];
+      }
+    c->queue_of_pipe[j] = q >= 0 ? q : nq++;
+  }
+  c->n_queues = std::max(1, nq);
+  // the sampler's unit u runs on stream pipe_order[u]: streams of different queues first, so that as many units as
+  // there are queues really run side by side
+  int k = 0;
+  bool taken[kMaxPipes] = {};
+  for (int round = 0; k < c->n_streams; ++round) {
+    bool seen[kMaxPipes] = {};
+    for (int pi = 0; pi < c->n_streams; ++pi)
+      if (!taken[pi] && !seen[c->queue_of_pipe[pi]]) {
+        seen[c->queue_of_pipe[pi]] = true;
+        taken[pi] = true;
+        c->pipe_order[k++] = pi;
+      }
+  }
+  return ABD_OK;
+}
+
+// the HIP stream (pipe) of the native sampler's unit u
+inline int unit_pipe(const abd_ctx* c, int u) { return c->pipe_order[u % c->n_streams]; }
 
 // queue the standalone fixed-order sum of a launch whose partials are still pending
 int flush_pipe(abd_ctx* c, int pi) {
@@ -1358,6 +1413,12 @@ int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t res
 }
 
 int64_t abd_wait_fallbacks(abd_ctx* c) { return c ? c->wait_fallbacks : -1; }
+int abd_stream_queues(abd_ctx* c, int32_t* queue_of_stream, int32_t n) {
+  if (!c || !queue_of_stream) return fail(ABD_ERR_ARG, "NULL argument");
+  if (int rc = probe_stream_queues(c)) return rc;
+  for (int i = 0; i < n; ++i) queue_of_stream[i] = i < c->n_streams ? c->queue_of_pipe[i] : -1;
+  return ABD_OK;
+}
 int abd_resident_stats(abd_ctx* c, int64_t* launches, int64_t* commands, int64_t* restarts) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
   if (launches) *launches = c->resident_launches;
@@ -1560,7 +1621,7 @@ int resident_eval(abd_sampler* s, int u, int32_t chain, const double* theta) {
     resident_write(r, cp, c->seq);
     return ABD_OK;
   }
-  const int pi = u % c->n_streams;
+  const int pi = unit_pipe(c, u);
   abd_ctx::Pipe& pp = c->pipe[pi];
   if (int frc = flush_pipe(c, pi)) return frc;
   if (pi > 0) pp.busy = true;
@@ -1625,7 +1686,7 @@ void resident_quit(abd_sampler* s, int u) {
 int resident_recover(abd_sampler* s, int u) {
   abd_ctx* c = s->c;
   abd_sampler::Resident& r = s->res[(size_t)u];
-  HIP_TRY(hipStreamSynchronize(c->pipe[u % c->n_streams].st));
+  HIP_TRY(hipStreamSynchronize(c->pipe[unit_pipe(c, u)].st));
   HIP_TRY(hipMemset(r.relay + ABD_RES_RELAY_WORDS, 0, sizeof(unsigned long long)));
   r.rounds = 0;
   r.cur ^= 1;
@@ -1675,11 +1736,12 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   if (const char* e = std::getenv("ABD_GROUP_BLOCKS_PER_CU")) c->group_blocks = std::max(1, std::min(c->n_cu * std::atoi(e), c->blocks_max));
   // the starting points through the launch shape the units will use
   rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
+  if (!rc && (n + s->unit - 1) / s->unit > 1 && !(std::getenv("ABD_PROBE_QUEUES") && std::atoi(std::getenv("ABD_PROBE_QUEUES")) == 0)) rc = probe_stream_queues(c);
   if (!rc) rc = resident_setup(s);
   for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
     const int m = std::min(s->unit, n - lo);
-    rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, u % c->n_streams);
-    if (!rc) rc = wait_rows(c, kSyncSlot + u, m, c->seq, c->pipe[u % c->n_streams].st);
+    rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, unit_pipe(c, u));
+    if (!rc) rc = wait_rows(c, kSyncSlot + u, m, c->seq, c->pipe[unit_pipe(c, u)].st);
     if (!rc) rc = fetch_slot(c, kSyncSlot + u, s->lp.data() + lo, s->gr.data() + (size_t)lo * ABD_N_THETA);
   }
   if (rc) {
@@ -1814,11 +1876,11 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   HIP_TRY(hipSetDevice(c->device));
   if (int frc = flush_ring(c)) return frc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first
-  auto stream_of = [&](int u) { return c->pipe[u % c->n_streams].st; };
+  auto stream_of = [&](int u) { return c->pipe[unit_pipe(c, u)].st; };
   // evaluate the points th[0 .. m) of the unit's chains who[0 .. m)
   auto launch_eval = [&](int u) -> int {
     Unit& un = units[(size_t)u];
-    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, u % c->n_streams);
+    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u));
     if (rc) return rc;
     un.tag = c->seq;
     return ABD_OK;

@@ -691,6 +691,21 @@ __global__ __launch_bounds__(ABD_FIN_THREADS) void abd_finalize_kernel(const dou
                                   out + blockIdx.x * ABD_NOUT, sm, threadIdx.x, tag);
 }
 
+// One wave that stays on the device for `ticks` of the 100 MHz s_memrealtime counter and says when (abd_capi.hip:
+// probe_stream_queues -- which of the context's HIP streams can have kernels on the device at the same time)
+__global__ void abd_spin_kernel(unsigned long long* out, unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(16);
+    t = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = t0;
+    out[1] = t;
+  }
+}
+
 // device result ring -> mapped host memory, for stream-ordered launches (one flush per abd_wait)
 __global__ void abd_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];

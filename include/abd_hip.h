@@ -253,6 +253,10 @@ int64_t abd_wait_fallbacks(abd_ctx* ctx);
  * launched, evaluations they served, and relaunches after a kernel left on its own because the host did not send a
  * command within its time-out (harmless, but expected to stay 0 on an idle machine).  Any pointer may be NULL. */
 int abd_resident_stats(abd_ctx* ctx, int64_t* launches, int64_t* commands, int64_t* restarts);
+/* HIP multiplexes its streams over a few hardware queues, and kernels of streams that share a queue run one after the
+ * other.  Measures (once per context, ~0.5 ms) which of the context's n <= 8 streams share one: streams with the same
+ * number in queue_of_stream[] do.  The native sampler gives its units streams of different queues first. */
+int abd_stream_queues(abd_ctx* ctx, int32_t* queue_of_stream, int32_t n);
 int abd_kernel_time(abd_ctx* ctx, double* total_ms, int64_t* launches, int32_t reset);
 
 /* Tuning hook (benchmarks / experiments): number of 256-thread workgroups of the evaluation grid

@@ -124,6 +124,7 @@ SYMBOLS = {
     "abd_wait_fallbacks": (C.c_int64, [_P]),
     "abd_resident_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "abd_stream_queues": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
+    "abd_n_pipes": (C.c_int, [_P]),
     "abd_is_dense": (C.c_int, [_P]),
 }
 
@@ -270,6 +271,11 @@ class Context:
         return bool(self._lib.abd_is_dense(self._h))
 
     @property
+    def n_pipes(self) -> int:
+        """HIP streams that stream-ordered dense launches rotate over."""
+        return int(self._lib.abd_n_pipes(self._h))
+
+    @property
     def wait_fallbacks(self) -> int:
         """Synchronous calls that had to fall back from the polled completion tag to a stream synchronise (expect 0)."""
         return int(self._lib.abd_wait_fallbacks(self._h))
@@ -397,11 +403,16 @@ class Context:
         _check(self._lib, self._lib.abd_fetch(self._h, slot, _ptr(lp, C.c_double), _ptr(g, C.c_double)))
         return lp, g
 
-    def fetch_many(self, slots, n_per_slot: int):
-        """fetch() for several slots at once -> (len(slots), n_per_slot) logp and (len(slots), n_per_slot, 17) grad."""
+    def fetch_many(self, slots, n_per_slot: int, out_lp=None, out_g=None):
+        """fetch() for several slots at once -> (len(slots), n_per_slot) logp and (len(slots), n_per_slot, 17) grad;
+        ``out_lp`` / ``out_g``: C-contiguous float64 arrays of those shapes to write into instead of new ones."""
         sl = _as(slots, np.int32)
-        lp = np.empty((sl.size, n_per_slot))
-        g = np.empty((sl.size, n_per_slot, N_THETA))
+        lp = np.empty((sl.size, n_per_slot)) if out_lp is None else out_lp
+        g = np.empty((sl.size, n_per_slot, N_THETA)) if out_g is None else out_g
+        if out_lp is not None or out_g is not None:
+            for a, shape in ((lp, (sl.size, n_per_slot)), (g, (sl.size, n_per_slot, N_THETA))):
+                if a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
+                    raise ValueError(f"output array must be C-contiguous float64 of shape {shape}")
         _check(self._lib, self._lib.abd_fetch_many(self._h, sl.size, _ptr(sl, C.c_int32), _ptr(lp, C.c_double), _ptr(g, C.c_double)))
         return lp, g
 

@@ -65,11 +65,23 @@ struct ChainSlot {
   bool set = false;
 };
 
+struct Transformed {
+  double p, perm_n, temp_n, rho_n, init_n, perm_s, rho_s, q, tinf, tvac, init_s;
+  double b_n, d_n, sig_n, b_s, d_s, sig_s;
+};
+
+// see prepare()
+struct HostTerms {
+  Transformed tr;
+  double L0[4], L1[4];  // -softplus(-t), -softplus(t) of theta[0], [3], [6], [7]
+};
+
 struct ResultSlot {
   int n = 0;
   bool grad = true;
   std::vector<int32_t> chains;
   std::vector<double> theta;  // n x 17
+  std::vector<HostTerms> host;  // n: the host-side terms of every theta, computed when the evaluation is queued
 };
 
 }  // namespace
@@ -117,7 +129,7 @@ struct abd_ctx {
     double tag = 0.0;
     bool busy = false;  // pipe 1: work queued since the last join with pipe 0
   } pipe[kMaxPipes];
-  int n_pipes = 3;        // streams that stream-ordered dense launches rotate over (1 = everything on the context's stream)
+  int n_pipes = 4;        // streams that stream-ordered dense launches rotate over (1 = everything on the context's stream); at most one per hardware queue
   int n_streams = kMaxPipes;  // pipes that exist (the native sampler gives every chain a stream: chain k -> pipe k mod 8)
   int n_sync_slots = 4;   // private result rows of synchronous calls (slot kSyncSlot) and of the sampler's chains in flight
   int pipe_blocks = 0;    // dense grid of a launch that shares the chip with n_pipes - 1 others
@@ -169,11 +181,6 @@ struct abd_ctx {
 
 namespace {
 
-struct Transformed {
-  double p, perm_n, temp_n, rho_n, init_n, perm_s, rho_s, q, tinf, tvac, init_s;
-  double b_n, d_n, sig_n, b_s, d_s, sig_s;
-};
-
 inline double sigmoid(double t) { return 1.0 / (1.0 + std::exp(-t)); }
 inline double softplus(double t) { return std::max(t, 0.0) + std::log1p(std::exp(-std::fabs(t))); }
 
@@ -199,6 +206,20 @@ Transformed transform(const double* t) {
   return c;
 }
 
+// Everything transcendental that one theta needs on the host -- the backward transforms and the softplus pairs of the four
+// logit-transformed variables -- computed once, when the evaluation is QUEUED (the host is ahead of the device then), so
+// that fetching a result is a few dozen multiply-adds (at config 3 the fetch of a region's results was 4 % of the region).
+HostTerms prepare(const double* t) {
+  HostTerms h;
+  h.tr = transform(t);
+  const int k4[4] = {0, 3, 6, 7};
+  for (int q = 0; q < 4; ++q) {
+    h.L0[q] = -softplus(-t[k4[q]]);
+    h.L1[q] = -softplus(t[k4[q]]);
+  }
+  return h;
+}
+
 // Priors + transform log-Jacobians in closed form, and their gradient.
 //   p ~ Beta(1, G-1), i_raw ~ Bernoulli(p)                         abd.py:424-427
 //   ab_n_perm/temp ~ Gamma, ab_n_rho ~ Beta(10,1), ab_n_init ~ N  abd.py:329-340
@@ -220,7 +241,7 @@ double prior_constant(int G) {
   return v;
 }
 
-double priors(const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/,
+double priors(const HostTerms& h, const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/,
               double prior_const) {
   double lp = prior_const;
   if (g) std::fill(g, g + ABD_N_THETA, 0.0);
@@ -229,7 +250,7 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
     b = mu / (sd * sd);
   };
   {  // theta0
-    const double L0 = -softplus(-t[0]), L1 = -softplus(t[0]), p = sigmoid(t[0]);
+    const double L0 = h.L0[0], L1 = h.L1[0], p = h.tr.p;
     const double bm1 = (double)(G - 1) - 1.0;
     lp += (bm1 == 0.0 ? 0.0 : bm1 * L1) + L0 + L1 + n1 * L0 + (cells - n1) * L1;
     if (g) g[0] = (1.0 + n1) * (1.0 - p) - p * (bm1 + 1.0 + (cells - n1));
@@ -239,17 +260,18 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
   for (int q = 0; q < 5; ++q) {
     double al, be;
     gamma_ab(gmu[q], 0.5, al, be);
-    const double x = std::exp(t[gk[q]]);
+    const double gx[5] = {h.tr.perm_n, h.tr.temp_n, h.tr.perm_s, h.tr.tinf, h.tr.tvac};  // exp(t[1]), [2], [5], [8], [9]
+    const double x = gx[q];
     lp += al * t[gk[q]] - be * x;
     if (g) g[gk[q]] = al - be * x;
   }
   for (int k : {3, 6}) {
-    const double L0 = -softplus(-t[k]), L1 = -softplus(t[k]), r = sigmoid(t[k]);
+    const double L0 = h.L0[k == 3 ? 1 : 2], L1 = h.L1[k == 3 ? 1 : 2], r = k == 3 ? h.tr.rho_n : h.tr.rho_s;
     lp += 9.0 * L0 + L0 + L1;
     if (g) g[k] = 10.0 * (1.0 - r) - r;
   }
   {
-    const double L0 = -softplus(-t[7]), L1 = -softplus(t[7]), q = sigmoid(t[7]);
+    const double L0 = h.L0[3], L1 = h.L1[3], q = h.tr.q;
     lp += L0 + L1 + m1 * L0 + (N - m1) * L1;
     if (g) g[7] = (1.0 + m1) * (1.0 - q) - q * (1.0 + (N - m1));
   }
@@ -262,7 +284,7 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
     if (g) g[nk[q]] = -z / nsd[q];
   }
   for (int k : {13, 16}) {
-    const double x = std::exp(t[k]);
+    const double x = k == 13 ? h.tr.sig_n : h.tr.sig_s;
     lp += -x + t[k];
     if (g) g[k] = -x + 1.0;
   }
@@ -272,13 +294,14 @@ double priors(const double* t, int G, double cells, double n1, double N, double 
 // Combine the device sums of one chain with the host-side terms.  The device accumulates
 //   Q2 = sum q^2, H.. = sums of h' = q s (1 - s), QS = sum q s   with q = od - d s   (abd_kernels.hpp)
 // so  ll = -1/2 Q2 / sigma^2 - K (log sigma + 1/2 log 2 pi),  d ll / d a_k = -b (d / sigma^2) h'_k.
-void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad, bool with_priors = true) {
-  const Transformed tr = transform(t);
+void assemble(const abd_ctx* c, const HostTerms& h, const double* t, const double* sums, double* logp, double* grad,
+              bool with_priors = true) {
+  const Transformed& tr = h.tr;
   const double n1 = sums[ABD_NACC], m1 = sums[ABD_NACC + 1];
   const double cells = (double)c->G * (double)c->N;
   double lp = 0.0;
   if (with_priors)
-    lp = priors(t, c->G, cells, n1, (double)c->N, m1, grad, c->prior_const);
+    lp = priors(h, t, c->G, cells, n1, (double)c->N, m1, grad, c->prior_const);
   else if (grad)
     std::fill(grad, grad + ABD_N_THETA, 0.0);
   const double Kn = (double)c->n.K, Ks = (double)c->s.K;
@@ -304,8 +327,11 @@ void assemble(const abd_ctx* c, const double* t, const double* sums, double* log
   }
 }
 
-ChainPar chain_par(const abd_ctx* c, int chain, const double* t) {
-  const Transformed tr = transform(t);
+void assemble(const abd_ctx* c, const double* t, const double* sums, double* logp, double* grad, bool with_priors = true) {
+  assemble(c, prepare(t), t, sums, logp, grad, with_priors);
+}
+
+ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr) {
   ChainPar p;
   p.perm_n = tr.perm_n;
   p.temp_n = tr.temp_n;
@@ -322,6 +348,7 @@ ChainPar chain_par(const abd_ctx* c, int chain, const double* t) {
   p.waner = c->slots[chain].waner;
   return p;
 }
+ChainPar chain_par(const abd_ctx* c, int chain, const double* t) { return chain_par(c, chain, transform(t)); }
 
 void base_args(const abd_ctx* c, EvalArgs& a) {
   std::memset(&a, 0, sizeof a);
@@ -555,11 +582,12 @@ int flush_pending(abd_ctx* c) {
 
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
-                  bool deferred = false, int force_pipe = -1) {
+                  bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr) {
   EvalArgs a;
   base_args(c, a);
   a.n_chains = n;
-  for (int k = 0; k < n; ++k) a.ch[k] = chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
+  for (int k = 0; k < n; ++k)
+    a.ch[k] = host ? chain_par(c, chains[k], host[k].tr) : chain_par(c, chains[k], theta + (size_t)k * ABD_N_THETA);
   const bool lanes = !c->dense && c->obs_lanes;
   int cpw = lanes ? 1 : pick_cpw(c, n);
   if (!lanes && !c->dense) cpw = std::min(cpw, 2);  // wave-per-individual list kernel: see launch_sparse
@@ -585,7 +613,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   if (force_pipe >= 0) {
     pi = force_pipe;  // the caller keeps several synchronous groups in flight, one per pipe (abd_sampler_run_record)
   } else if (rotate) {
-    pi = c->next_pipe;
+    pi = c->pipe_order[c->next_pipe];  // streams of different hardware queues (identity until probe_stream_queues has run)
     c->next_pipe = (c->next_pipe + 1) % c->n_pipes;
   } else if (int jrc = join_pipes(c)) {
     return jrc;
@@ -720,6 +748,8 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   r.grad = grad;
   r.chains.assign(chains, chains + n);
   r.theta.assign(theta, theta + (size_t)n * ABD_N_THETA);
+  r.host.resize((size_t)n);
+  for (int k = 0; k < n; ++k) r.host[(size_t)k] = prepare(theta + (size_t)k * ABD_N_THETA);
   // a synchronous call lets the finalize kernel write straight into mapped host memory (one PCIe write,
   // ~3 us inside the kernel); stream-ordered calls write device memory and are flushed together at abd_wait
   double* rows = (deferred ? c->d_ring : c->d_out) + (size_t)slot * c->n_slots * ABD_NOUT;
@@ -734,7 +764,8 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   }
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
-    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred, force_pipe);
+    rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred, force_pipe,
+                       r.host.data() + k0);
     if (!rc && force_pipe >= 0) rc = flush_pipe(c, force_pipe);  // a group's fixed-order sum follows on its own stream
     if (rc) return rc;
   }
@@ -747,7 +778,7 @@ int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_prior
   if (r.n == 0) return fail(ABD_ERR_STATE, "result slot %d is empty", slot);
   const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
   for (int k = 0; k < r.n; ++k)
-    assemble(c, r.theta.data() + (size_t)k * ABD_N_THETA, rows + (size_t)k * ABD_NOUT, logp + k,
+    assemble(c, r.host[(size_t)k], r.theta.data() + (size_t)k * ABD_N_THETA, rows + (size_t)k * ABD_NOUT, logp + k,
              (grad && r.grad) ? grad + (size_t)k * ABD_N_THETA : nullptr, with_priors);
   return ABD_OK;
 }
@@ -1027,7 +1058,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   }
   c->pipe[0].st = c->stream;
   if (const char* e = std::getenv("ABD_TWO_PIPES")) c->n_pipes = std::atoi(e) != 0 ? 2 : 1;
-  if (const char* e = std::getenv("ABD_PIPES")) c->n_pipes = std::max(1, std::min(4, std::atoi(e)));
+  if (const char* e = std::getenv("ABD_PIPES")) c->n_pipes = std::max(1, std::min(6, std::atoi(e)));
   if (!c->dense) c->n_pipes = 1;  // only the dense kernel has a grid for sharing the chip; the others just overlap
   c->n_streams = kMaxPipes;
   c->n_sync_slots = std::max(4, c->n_slots);
@@ -1067,6 +1098,15 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
   c->results.resize((size_t)kResultSlots + c->n_sync_slots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
+  if (c->dense && c->n_pipes > 1) {
+    // the pipes must sit on different hardware queues (two launches in one queue run one after the other: 4 pipes on
+    // streams 0..3, two of which share a queue here, gave 143 k evals/s at config 3 against 192 k on streams 0, 1, 2, 5)
+    if (int prc = probe_stream_queues(c)) {
+      free_ctx(c);
+      return prc;
+    }
+    c->n_pipes = std::min(c->n_pipes, c->n_queues);
+  }
 #undef CREATE_TRY
   *out = c;
   return ABD_OK;
@@ -1084,6 +1124,7 @@ int abd_device_name(abd_ctx* c, char* buf, int32_t buflen) {
 }
 
 int abd_is_dense(abd_ctx* c) { return c && c->dense ? 1 : 0; }
+int abd_n_pipes(abd_ctx* c) { return c ? c->n_pipes : -1; }
 
 int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_t* waner) {
   if (!c || !i_raw || !waner) return fail(ABD_ERR_ARG, "NULL argument");
@@ -1364,7 +1405,7 @@ int abd_set_launch_config(abd_ctx* c, int32_t blocks, int32_t chains_per_wave) {
 
 int abd_theta_prior(abd_ctx* c, const double* theta, double* logp, double* grad) {
   if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
-  *logp = priors(theta, c->G, 0.0, 0.0, 0.0, 0.0, grad, c->prior_const);
+  *logp = priors(prepare(theta), theta, c->G, 0.0, 0.0, 0.0, 0.0, grad, c->prior_const);
   return ABD_OK;
 }
 
@@ -1613,7 +1654,8 @@ int resident_eval(abd_sampler* s, int u, int32_t chain, const double* theta) {
   rs.grad = true;
   rs.chains.assign(1, chain);
   rs.theta.assign(theta, theta + ABD_N_THETA);
-  const ChainPar cp = chain_par(c, chain, theta);
+  rs.host.assign(1, prepare(theta));
+  const ChainPar cp = chain_par(c, chain, rs.host[0].tr);
   if (r.live) {
     c->seq += 1.0;
     r.rounds += 1;

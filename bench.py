@@ -153,6 +153,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
+    slot_ids = np.arange(nslots, dtype=np.int32)
+
     def run_steps(lo, hi, out_lp=None, out_g=None):
         """enqueue steps [lo, hi) stream-ordered; fetch in windows of the result ring"""
         s = lo
@@ -161,10 +163,11 @@ def main():
             for k in range(s, e):
                 ctx.enqueue(k - s, chains, thetas[k])
             ctx.wait()
-            lp, g = ctx.fetch_many(np.arange(e - s), C)  # host side: prior terms + scaling of the device sums
+            # host side: prior terms + scaling of the device sums, written straight into the caller's arrays
             if out_lp is not None:
-                out_lp[s - lo:e - lo] = lp
-                out_g[s - lo:e - lo] = g
+                ctx.fetch_many(slot_ids[:e - s], C, out_lp[s - lo:e - lo], out_g[s - lo:e - lo])
+            else:
+                ctx.fetch_many(slot_ids[:e - s], C)
             s = e
 
     def warm(seconds):
@@ -275,8 +278,8 @@ def main():
         bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
         traffic=pipe_prof.get("hbm_bytes_per_launch"), kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel",
         kernel_us=round(w_avg_s * 1e6, 3), launches=int(w_n),
-        launch_shape="stream-ordered, as timed: launches rotate over 3 HIP streams, 1 workgroup per CU each; device time "
-                     "from HIP events around each window of K launches / K",
+        launch_shape=f"stream-ordered, as timed: launches rotate over {ctx.n_pipes} HIP streams on different hardware queues, "
+                     "1 workgroup per CU each; device time from HIP events around each window of K launches / K",
         algorithmic_bytes_per_launch=int(alg_bytes), survey_bytes_per_launch=int(survey_bytes), evals_per_launch=C,
         isolated=dict(kernel_us=round(k_avg_s * 1e6, 3), achieved=round(iso_achieved, 2), frac=round(iso_achieved / HBM_PEAK_GBS, 4),
                       launches=int(k_n), traffic=prof.get("hbm_bytes_per_launch"),

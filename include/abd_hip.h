@@ -131,9 +131,9 @@ int abd_logp_dlogp_batch(abd_ctx* ctx, int32_t n, const int32_t* chains, const d
 /* Stream-ordered form: enqueue returns as soon as the launch is queued; results land in result slot
  * `slot` (0 <= slot < abd_n_result_slots) and are read back with abd_fetch after abd_wait.
  * A NUTS driver that runs several chain groups uses this to overlap host work with the device.
- * Dense cohorts: consecutive enqueued launches rotate over three HIP streams (launch k+3 sums launch k's
- * partials), each with a quarter of the workgroups of a synchronous launch, so three share the chip instead
- * of one draining it between launches; abd_wait joins them.
+ * Dense cohorts: consecutive enqueued launches rotate over up to four HIP streams that sit on different hardware
+ * queues (measured at abd_create; launch k+4 sums launch k's partials), each with a quarter of the workgroups of a
+ * synchronous launch, so four share the chip instead of one draining it between launches; abd_wait joins them.
  * Synchronous calls may be interleaved: they use rows of their own and leave every result slot alone.
  * Each form is bit-reproducible; the two forms use different launch shapes and agree to rounding (~1e-15). */
 int abd_n_result_slots(abd_ctx* ctx);
@@ -237,7 +237,7 @@ int abd_set_individual_offset(abd_ctx* ctx, int64_t first_individual);
 
 /* Measurement hooks used by bench.py.  mode 1: every evaluation kernel launch is bracketed by HIP events on
  * the stream it is launched on, and stream-ordered launches all go to ONE stream with the full grid (normally
- * they rotate over three, so that launches share the chip: a launch's own duration is only meaningful when
+ * they rotate over four, so that launches share the chip: a launch's own duration is only meaningful when
  * nothing else is in flight) -- the isolated kernel.  mode 2: the launch shape is left alone and HIP events
  * bracket every WINDOW of stream-ordered launches (first abd_logp_dlogp_batch_enqueue after an abd_wait ..
  * every stream joined at the next abd_wait) -- device time per launch as a stream-ordered caller runs them.
@@ -272,6 +272,8 @@ int64_t abd_algorithmic_bytes(abd_ctx* ctx, int32_t n_chains);
 
 /* 1 if the observation panels were recognised as dense (one S and one N reading in every cell). */
 int abd_is_dense(abd_ctx* ctx);
+/* HIP streams that stream-ordered dense launches rotate over (1 for cohorts kept as observation lists). */
+int abd_n_pipes(abd_ctx* ctx);
 
 #ifdef __cplusplus
 }

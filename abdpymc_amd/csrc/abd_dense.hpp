@@ -326,13 +326,21 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
   // that starts inside an individual's gaps reads them, and only entries up to its start gap.
   const int n_entries = CB == ABD_WAVES_PER_BLOCK ? g0_first + 1 : tstride;
-  if (sub == 0) {
+  // the 2^(j/1024) table is requested first and stored last: its loads are in flight while the power tables are built
+  double e2v[ABD_EXP2_TAB / ABD_BLOCK];
+#pragma unroll
+  for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) e2v[q] = a.exp2_tab[q * ABD_BLOCK + tid];
+  if (NSUB >= 2) {  // a chain has two or four waves in this workgroup: one fills its rho_n table, another its rho_s table
+    if (sub == 0) fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
+    if (sub == 1) fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
+  } else {
     fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
     fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
   }
   if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, n_entries, lane);
   ABD_STAMP(2);
-  for (int e = tid; e < ABD_EXP2_TAB; e += ABD_BLOCK) tab_e2[e] = a.exp2_tab[e];
+#pragma unroll
+  for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) tab_e2[q * ABD_BLOCK + tid] = e2v[q];
   ABD_STAMP(3);
 
   double acc[16];

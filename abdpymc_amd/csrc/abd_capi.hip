@@ -151,6 +151,10 @@ struct abd_ctx {
   double prior_const = 0.0;
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots + n_sync_slots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out
+  double* h_done = nullptr;    // pinned + mapped: completion tag of a small stream-ordered flush (abd_wait polls it)
+  double* d_done = nullptr;
+  double flush_tag = 0.0;      // tag of the flush in flight, 0 = none
+  bool wait_poll = true;       // ABD_WAIT_POLL=0: abd_wait always synchronises the stream
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
   unsigned int* d_work = nullptr;          // [2][n_slots] work queue heads of abd_gibbs_dense_kernel (second half: per-chain sweeps of the sampler)
   unsigned long long* d_counts_chain = nullptr;  // [n_slots][2] counts of the sampler's per-chain sweeps ...
@@ -694,9 +698,18 @@ int flush_ring(abd_ctx* c) {
   if (c->ring_lo < c->ring_hi) {
     const size_t row = (size_t)c->n_slots * ABD_NOUT;
     const int64_t count = (int64_t)(c->ring_hi - c->ring_lo) * row;
-    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 1024);
-    hipLaunchKernelGGL(abd_copy_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_ring + (size_t)c->ring_lo * row,
-                       c->d_out + (size_t)c->ring_lo * row, count);
+    if (c->wait_poll && count <= 16384) {
+      // small flush: one workgroup copies and then raises a tag the host polls (abd_wait) -- a stream synchronise
+      // returns several microseconds after the stream has drained
+      c->seq += 1.0;
+      c->flush_tag = c->seq;
+      hipLaunchKernelGGL(abd_copy_tag_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_ring + (size_t)c->ring_lo * row,
+                         c->d_out + (size_t)c->ring_lo * row, count, c->d_done, c->flush_tag);
+    } else {
+      const int blocks = (int)std::min<int64_t>((count + 255) / 256, 1024);
+      hipLaunchKernelGGL(abd_copy_kernel, dim3(blocks), dim3(256), 0, c->stream, c->d_ring + (size_t)c->ring_lo * row,
+                         c->d_out + (size_t)c->ring_lo * row, count);
+    }
     HIP_TRY(hipGetLastError());
     c->ring_lo = c->ring_hi = 0;
   }
@@ -899,6 +912,7 @@ void free_ctx(abd_ctx* c) {
     if (c->pipe[pi].st) (void)hipStreamDestroy(c->pipe[pi].st);
   }
   if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_done) (void)hipHostFree(c->h_done);
   if (c->d_ring) (void)hipFree(c->d_ring);
   if (c->d_counts) (void)hipFree(c->d_counts);
   if (c->d_work) (void)hipFree(c->d_work);
@@ -1087,6 +1101,10 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipHostMalloc(&c->h_out, out_bytes, hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(c->h_out, 0, out_bytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
+  CREATE_TRY(hipHostMalloc(&c->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(c->h_done, 0, 64);
+  CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_done, c->h_done, 0));
+  if (const char* e = std::getenv("ABD_WAIT_POLL")) c->wait_poll = std::atoi(e) != 0;
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
   CREATE_TRY(hipMalloc(&c->d_work, (size_t)2 * c->n_slots * sizeof(unsigned int)));
@@ -1174,8 +1192,22 @@ int abd_logp_dlogp_batch_enqueue(abd_ctx* c, int32_t slot, int32_t n, const int3
 int abd_wait(abd_ctx* c) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
+  c->flush_tag = 0.0;  // only a flush queued by THIS call may stand in for the synchronise
   int rc = flush_ring(c);
   if (rc) return rc;
+  if (c->flush_tag != 0.0) {  // the flush raises a tag in mapped memory when it is done
+    const double tag = c->flush_tag;
+    c->flush_tag = 0.0;
+    volatile const double* done = c->h_done;
+    for (int spin = 0; spin < 4000000; ++spin) {
+      if (*done == tag) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return ABD_OK;
+      }
+      __builtin_ia32_pause();
+    }
+    c->wait_fallbacks++;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
 }

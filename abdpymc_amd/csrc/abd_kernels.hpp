@@ -706,6 +706,17 @@ __global__ void abd_spin_kernel(unsigned long long* out, unsigned long long tick
   }
 }
 
+// The same copy by ONE workgroup, for small flushes, followed by a completion tag in mapped host memory (every thread
+// fences its own stores at system scope before the barrier, thread 0 then releases the tag): abd_wait polls the tag
+// instead of synchronising the stream.
+__global__ __launch_bounds__(1024) void abd_copy_tag_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n,
+                                                            double* done, double tag) {
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(done, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // device result ring -> mapped host memory, for stream-ordered launches (one flush per abd_wait)
 __global__ void abd_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];

@@ -382,7 +382,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64",  # the type the path computes in; with config.storage = "f32" only the panels in HBM are fp32
             "data": "synthetic",
             "config": {"workload": cfg["name"], "n_inds": N, "n_gaps": G, "storage": cfg["storage"],
                        "chains_per_gpu": C, "total_chains": C * world, "splits": list(splits or ()),

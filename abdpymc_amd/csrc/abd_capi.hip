@@ -49,6 +49,14 @@ constexpr int kMaxPipes = 8;             // HIP streams of a context
 constexpr int kMinRows = 4;
 constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
+// ABD_SAMPLER_PROFILE: time the host spends inside hipLaunchKernelGGL for evaluation launches and their sums
+struct LaunchProfile {
+  bool on = false;
+  double eval_s = 0.0, sum_s = 0.0;
+  long evals = 0, sums = 0;
+};
+LaunchProfile g_launch_profile;
+
 struct AntigenDev {
   int64_t K = 0;
   void* y = nullptr;       // sparse: R[K], sorted by (ind, gap)
@@ -556,7 +564,13 @@ inline int unit_pipe(const abd_ctx* c, int u) { return c->pipe_order[u % c->n_st
 int flush_pipe(abd_ctx* c, int pi) {
   abd_ctx::Pipe& p = c->pipe[pi];
   if (p.on) {
+    std::chrono::steady_clock::time_point lp0;
+    if (g_launch_profile.on) lp0 = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(abd_finalize_kernel, dim3(p.n), dim3(ABD_FIN_THREADS), 0, p.st, p.partials[p.buf], p.blocks, p.out, p.tag);
+    if (g_launch_profile.on) {
+      g_launch_profile.sum_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - lp0).count();
+      g_launch_profile.sums++;
+    }
     HIP_TRY(hipGetLastError());
     p.on = false;
   }
@@ -665,6 +679,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (c->timing == 2 && deferred) c->win_launches++;
   hipError_t le;
+  std::chrono::steady_clock::time_point lp0;
+  if (g_launch_profile.on) lp0 = std::chrono::steady_clock::now();
   if (lanes)
     le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, pp.st, a)
                                      : launch_obs<double>(grad, grid, lds, pp.st, a);
@@ -674,6 +690,10 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   else
     le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, pp.st, a)
                                      : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);
+  if (g_launch_profile.on) {
+    g_launch_profile.eval_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - lp0).count();
+    g_launch_profile.evals++;
+  }
   if (c->timing == 1) HIP_TRY(hipEventRecord(e1, pp.st));
   HIP_TRY(le);
   c->seq += 1.0;
@@ -1199,14 +1219,16 @@ int abd_wait(abd_ctx* c) {
     const double tag = c->flush_tag;
     c->flush_tag = 0.0;
     volatile const double* done = c->h_done;
-    for (int spin = 0; spin < 4000000; ++spin) {
+    const auto t_poll = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
       if (*done == tag) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         return ABD_OK;
       }
       __builtin_ia32_pause();
+      // a long queue is not a fault: after a second of polling hand over to the (always correct) stream synchronise
+      if ((spin & 4095) == 4095 && std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(1)) break;
     }
-    c->wait_fallbacks++;
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return ABD_OK;
@@ -2056,6 +2078,8 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   }
   // ABD_SAMPLER_PROFILE=1: how much of the wall time the host thread spends handling results and queueing launches
   static const bool profile = std::getenv("ABD_SAMPLER_PROFILE") != nullptr;
+  g_launch_profile = LaunchProfile();
+  g_launch_profile.on = profile;
   using clk = std::chrono::steady_clock;
   const clk::time_point t_begin = clk::now();
   clk::time_point t_handle;
@@ -2157,6 +2181,10 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
                  n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
                  handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
                  handled ? 1e6 * prof_launch / handled : 0.0);
+    std::fprintf(stderr, "abd sampler: inside hipLaunchKernelGGL: %.2f us per evaluation launch (%ld), %.2f us per sum launch (%ld)\n",
+                 g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0, g_launch_profile.evals,
+                 g_launch_profile.sums ? 1e6 * g_launch_profile.sum_s / g_launch_profile.sums : 0.0, g_launch_profile.sums);
+    g_launch_profile.on = false;
   }
   // the context's stream continues behind everything the units queued
   for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;

@@ -12,7 +12,7 @@ once after the timed region and timed on its own (`gather_ms`).
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
 (`python -m torch.distributed.run ...`, before this process has touched the GPU) and passes rank 0's line on.
 
-Timed region: K steps enqueued stream-ordered (the library rotates them over three HIP streams so that
+Timed region: K steps enqueued stream-ordered (the library rotates them over four HIP streams so that
 launches share the chip instead of draining it one after the other), one wait, results fetched (host-side
 prior terms included), opened by barrier + device sync, closed by a device sync; MAX over ranks.  Inputs
 are resident in HBM before it starts.  The K-step region is repeated R times (until >= 0.25 s of timed work,

@@ -515,31 +515,44 @@ int range_table(abd_ctx* c, int blocks, int nsub, const int32_t** out) {
 int probe_stream_queues(abd_ctx* c) {
   if (c->n_queues > 0) return ABD_OK;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipDeviceSynchronize());
   unsigned long long* d = nullptr;
   HIP_TRY(hipMalloc(&d, (size_t)kMaxPipes * 2 * sizeof(unsigned long long)));
-  const unsigned long long ticks = 15000;  // 150 us
-  for (int pi = 0; pi < c->n_streams; ++pi) hipLaunchKernelGGL(abd_spin_kernel, dim3(1), dim3(64), 0, c->pipe[pi].st, d + 2 * pi, ticks);
-  hipError_t le = hipGetLastError();
-  if (le == hipSuccess) le = hipDeviceSynchronize();
-  unsigned long long h[kMaxPipes * 2] = {};
-  if (le == hipSuccess) le = hipMemcpy(h, d, sizeof(unsigned long long) * 2 * (size_t)c->n_streams, hipMemcpyDeviceToHost);
+  const int ns = c->n_streams;
+  // Stream pi's wave stays for 150 + 20 pi us, so the waves end at least 20 us apart and a wave that had to wait for a
+  // queue starts within a few us of exactly one earlier wave's end: it is behind that one.  A wave that starts while all
+  // earlier ones are still there has a queue to itself.  A host hiccup between two launches can make a stream look
+  // queued, never the other way round: up to three attempts, the one that finds the most queues counts.
+  int best_nq = 0, best[kMaxPipes] = {};
+  hipError_t le = hipSuccess;
+  for (int attempt = 0; attempt < 3 && best_nq < 4 && le == hipSuccess; ++attempt) {
+    le = hipDeviceSynchronize();
+    for (int pi = 0; pi < ns && le == hipSuccess; ++pi) {
+      hipLaunchKernelGGL(abd_spin_kernel, dim3(1), dim3(64), 0, c->pipe[pi].st, d + 2 * pi, 15000ull + 2000ull * (unsigned long long)pi);
+      le = hipGetLastError();
+    }
+    if (le == hipSuccess) le = hipDeviceSynchronize();
+    unsigned long long h[kMaxPipes * 2] = {};
+    if (le == hipSuccess) le = hipMemcpy(h, d, sizeof(unsigned long long) * 2 * (size_t)ns, hipMemcpyDeviceToHost);
+    if (le != hipSuccess) break;
+    int nq = 0, q_of[kMaxPipes] = {};
+    unsigned long long busy_until[kMaxPipes] = {};
+    for (int j = 0; j < ns; ++j) {
+      int q = -1;
+      for (int k = 0; k < nq && q < 0; ++k)
+        if (h[2 * j] + 300 >= busy_until[k] && h[2 * j] <= busy_until[k] + 800) q = k;  // started 0-8 us after queue k drained
+      if (q < 0) q = nq++;
+      q_of[j] = q;
+      busy_until[q] = h[2 * j + 1];
+    }
+    if (nq > best_nq) {
+      best_nq = nq;
+      std::copy(q_of, q_of + kMaxPipes, best);
+    }
+  }
   (void)hipFree(d);
   HIP_TRY(le);
-  int nq = 0;
-  for (int j = 0; j < c->n_streams; ++j) {
-    int q = -1;
-    for (int i = 0; i < j && q < 0; ++i)
-      if (h[2 * j] + ticks / 10 >= h[2 * i + 1] && c->queue_of_pipe[i] >= 0) {
-        // started (about) when stream i's wave ended or later: behind it in the same queue -- unless another stream
-        // of that queue explains it just as well, which is the same answer
-        bool overlaps_all_of_queue = false;
-        for (int k = 0; k < j; ++k)
-          if (c->queue_of_pipe[k] == c->queue_of_pipe[i] && h[2 * j] + ticks / 10 < h[2 * k + 1]) overlaps_all_of_queue = true;
-        if (!overlaps_all_of_queue) q = c->queue_of_pipe[i];
-      }
-    c->queue_of_pipe[j] = q >= 0 ? q : nq++;
-  }
+  const int nq = best_nq;
+  std::copy(best, best + kMaxPipes, c->queue_of_pipe);
   c->n_queues = std::max(1, nq);
   // the sampler's unit u runs on stream pipe_order[u]: streams of different queues first, so that as many units as
   // there are queues really run side by side

@@ -6,6 +6,8 @@
 #include "abd_kernels.hpp"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <chrono>
@@ -13,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -121,6 +124,7 @@ struct abd_ctx {
     int32_t* dev = nullptr;
   };
   std::vector<RangeTable> range_tables;
+  std::mutex range_mutex;  // range_table() may be reached from several sampler threads
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
   // A pipe = a HIP stream with its own pair of partial buffers and its own pending fixed-order sum.  Pipe 0 is
@@ -480,6 +484,7 @@ int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
 // one range per workgroup (nsub == 1) the first ABD_MAX_BATCH ranges -- the workgroups that may carry the fused
 // fixed-order sum of an earlier launch -- are fin_rows shorter and the others share the difference.
 int range_table(abd_ctx* c, int blocks, int nsub, const int32_t** out) {
+  std::lock_guard<std::mutex> lock(c->range_mutex);
   for (const auto& rt : c->range_tables)
     if (rt.blocks == blocks && rt.nsub == nsub) {
       *out = rt.dev;
@@ -613,7 +618,10 @@ int flush_pending(abd_ctx* c) {
 
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
-                  bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr) {
+                  bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr, double* seqp = nullptr) {
+  // completion tags: the context's sequence, or the caller's own (a sampler unit handled by its own host thread: its
+  // result rows are private, so its tags only have to be unique among themselves)
+  double& seq = seqp ? *seqp : c->seq;
   EvalArgs a;
   base_args(c, a);
   a.n_chains = n;
@@ -658,7 +666,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   if (fused_sum) {
     a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
     a.fin_out = d_out_rows;
-    a.fin_tag = c->seq + 1.0;
+    a.fin_tag = seq + 1.0;
   }
   a.fin_rows = c->fin_rows;
   a.xcd_remap = c->xcd_remap ? 1 : 0;
@@ -709,14 +717,14 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (c->timing == 1) HIP_TRY(hipEventRecord(e1, pp.st));
   HIP_TRY(le);
-  c->seq += 1.0;
+  seq += 1.0;
   if (fused_sum) return ABD_OK;
   pp.on = true;
   pp.buf = buf;
   pp.n = n;
   pp.blocks = blocks;
   pp.out = d_out_rows;
-  pp.tag = c->seq;
+  pp.tag = seq;
   if (!(c->dense && c->fuse_finalize)) return flush_pipe(c, pi);
   return ABD_OK;
 }
@@ -784,7 +792,7 @@ int check_chains(abd_ctx* c, int n, const int32_t* chains) {
 }
 
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
-                 int force_pipe = -1) {
+                 int force_pipe = -1, double* seqp = nullptr) {
   if (slot < 0 || slot >= kSyncSlot + c->n_sync_slots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
@@ -811,7 +819,7 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
     rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred, force_pipe,
-                       r.host.data() + k0);
+                       r.host.data() + k0, seqp);
     if (!rc && force_pipe >= 0) rc = flush_pipe(c, force_pipe);  // a group's fixed-order sum follows on its own stream
     if (rc) return rc;
   }
@@ -1582,6 +1590,9 @@ struct abd_sampler {
     int fails = 0;  // relaunches in a row without an answer
   };
   std::vector<Resident> res;
+  // one completion-tag sequence per unit, disjoint from the context's and from each other's (unit u: (u + 1) 2^40 + k)
+  std::vector<double> unit_seq;
+  int threads = 1;  // host threads that drive the units (sampler_run_units)
   bool resident = false;
   int res_blocks = 0;
   size_t res_lds = 0;
@@ -1688,6 +1699,7 @@ int resident_setup(abd_sampler* s) {
   s->res_cmd_timeout = (unsigned long long)(ms * 1e5);  // s_memrealtime: 100 MHz
   s->res_guard_timeout = s->res_cmd_timeout * 10ull + 10000000ull;
   s->resident = true;
+  s->threads = 1;  // the resident path shares the context's tag sequence
   return ABD_OK;
 }
 
@@ -1836,9 +1848,16 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // that never wait for each other; a small cohort is bound by the host's ~6 us per launch, which a unit's chains share
   // (measured, tools/probe_nuts_rate.py: config 3 -- 8 chains 88 k evals/s with units of 1, 82 k with 4; 16 chains 92 k / 112 k;
   // default cohort, 16 chains -- 152 k with units of 1, 334 k with 4, 359 k with 8)
-  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(2, std::min(8, (n + 3) / 4));
+  // With four host threads (observation lists, see below) the best split is four units -- one per thread and per
+  // hardware queue: default cohort, evaluations/s seen by NUTS with 4 / 8 / 16 chains 217 k / 339 k / 491 k against
+  // 166 k / 253 k / 300-370 k for the best split on one thread.
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(c->dense ? 2 : 1, std::min(8, (n + 3) / 4));
   if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
+  // host threads that drive the units: one for dense cohorts (bound by the device), up to four for observation lists
+  // (bound by the host's two launches per evaluation)
+  s->threads = c->dense ? 1 : 4;
+  if (const char* e = std::getenv("ABD_SAMPLER_THREADS")) s->threads = std::max(1, std::min(16, std::atoi(e)));
   // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers
   // must not depend on it
   c->group_blocks = std::min(c->dense_blocks, c->n_cu);
@@ -1982,6 +2001,11 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     std::vector<double> th, lp, gr;
   };
   std::vector<Unit> units((size_t)n_units);
+  const int T_all = std::max(1, std::min(s->threads, n_units));  // host threads (see below)
+  if (s->unit_seq.size() != (size_t)n_units) {
+    s->unit_seq.resize((size_t)n_units);
+    for (int u = 0; u < n_units; ++u) s->unit_seq[(size_t)u] = (double)(u + 1) * 1099511627776.0;  // (u + 1) 2^40
+  }
   HIP_TRY(hipSetDevice(c->device));
   if (int frc = flush_ring(c)) return frc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first
@@ -1989,9 +2013,10 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   // evaluate the points th[0 .. m) of the unit's chains who[0 .. m)
   auto launch_eval = [&](int u) -> int {
     Unit& un = units[(size_t)u];
-    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u));
+    double* seqp = T_all > 1 ? &s->unit_seq[(size_t)u] : nullptr;
+    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u), seqp);
     if (rc) return rc;
-    un.tag = c->seq;
+    un.tag = seqp ? *seqp : c->seq;
     return ABD_OK;
   };
   auto launch_tree = [&](int u) -> int {  // the next leapfrog of every tree of the unit that is still growing
@@ -2089,115 +2114,147 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
     if (int rc = launch_tree(u)) return rc;
   }
-  // ABD_SAMPLER_PROFILE=1: how much of the wall time the host thread spends handling results and queueing launches
+  // The units are driven by T host threads, thread t the units u = t (mod T): what a thread touches is private to its
+  // units (stream, result rows, tag sequence, chains, the caller's arrays per chain) or read-only, so the threads
+  // share nothing but the HIP runtime.  T = 1 for dense cohorts (the device bounds them), up to 4 for observation lists,
+  // where the host's two launches per evaluation (~7 us) are what bounds a single thread.
+  // ABD_SAMPLER_PROFILE=1: how much of the wall time a host thread spends handling results and queueing launches.
   static const bool profile = std::getenv("ABD_SAMPLER_PROFILE") != nullptr;
+  const int T = std::max(1, std::min(s->threads, n_units));
   g_launch_profile = LaunchProfile();
-  g_launch_profile.on = profile;
+  g_launch_profile.on = profile && T == 1;
   using clk = std::chrono::steady_clock;
-  const clk::time_point t_begin = clk::now();
-  clk::time_point t_handle;
-  double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0;
-  long handled = 0;
-  for (long spins = 0;;) {
-    bool any = false, progressed = false;
-    for (int u = 0; u < n_units; ++u) {
-      Unit& un = units[(size_t)u];
-      if (un.state == DONE) continue;
-      any = true;
-      if (progressed && profile) {  // close the previous unit's handling interval
-        busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
-        t_handle = clk::now();
-      }
-      if (!ready(u)) {
-        if (!(s->resident && s->res[(size_t)u].live && *(volatile unsigned int*)s->res[(size_t)u].status_h == 2u)) continue;
-        // the kernel gave up waiting (the host was away for longer than its time-out).  Once it has left for good, either
-        // the answer has landed after all (it may leave while the last workgroup is still summing) or the command was
-        // never seen: relaunch and ask again
-        if (int rc = resident_recover(s, u)) return rc;
-        if (!ready(u)) {
-          if (++s->res[(size_t)u].fails > 50) return fail(ABD_ERR_STATE, "the resident evaluation kernel of chain %d does not answer", un.ids[0]);
-          if (int rc = resident_eval(s, u, un.ids[0], un.th.data())) return rc;
-          un.tag = c->seq;
-          continue;
+  std::atomic<int> first_error{ABD_OK};
+  std::vector<std::string> errors((size_t)T);
+  auto worker = [&](int tid) -> int {
+    if (hipSetDevice(c->device) != hipSuccess) return fail(ABD_ERR_HIP, "hipSetDevice failed");
+    const clk::time_point t_begin = clk::now();
+    clk::time_point t_handle;
+    double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0;
+    long handled = 0;
+    for (long spins = 0;;) {
+      bool any = false, progressed = false;
+      if (first_error.load(std::memory_order_relaxed) != ABD_OK) return ABD_OK;  // another thread failed: stop queueing
+      for (int u = tid; u < n_units; u += T) {
+        Unit& un = units[(size_t)u];
+        if (un.state == DONE) continue;
+        any = true;
+        if (progressed && profile) {  // close the previous unit's handling interval
+          busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
+          t_handle = clk::now();
         }
-      }
-      if (profile && !progressed) t_handle = clk::now();
-      progressed = true;
-      ++handled;
-      if (s->resident) s->res[(size_t)u].fails = 0;
-      clk::time_point tp0;
-      if (profile) tp0 = clk::now();
-      if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
-      if (profile) {
-        const clk::time_point t1 = clk::now();
-        prof_fetch += std::chrono::duration<double>(t1 - tp0).count();
-        tp0 = t1;
-      }
-      if (un.state == EVAL) {
-        for (int q = 0; q < un.m; ++q)
-          s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+        if (!ready(u)) {
+          if (!(s->resident && s->res[(size_t)u].live && *(volatile unsigned int*)s->res[(size_t)u].status_h == 2u)) continue;
+          // the kernel gave up waiting (the host was away for longer than its time-out).  Once it has left for good,
+          // either the answer has landed after all (it may leave while the last workgroup is still summing) or the
+          // command was never seen: relaunch and ask again
+          if (int rc = resident_recover(s, u)) return rc;
+          if (!ready(u)) {
+            if (++s->res[(size_t)u].fails > 50) return fail(ABD_ERR_STATE, "the resident evaluation kernel of chain %d does not answer", un.ids[0]);
+            if (int rc = resident_eval(s, u, un.ids[0], un.th.data())) return rc;
+            un.tag = c->seq;
+            continue;
+          }
+        }
+        if (profile && !progressed) t_handle = clk::now();
+        progressed = true;
+        ++handled;
+        if (s->resident) s->res[(size_t)u].fails = 0;
+        clk::time_point tp0;
+        if (profile) tp0 = clk::now();
+        if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
         if (profile) {
           const clk::time_point t1 = clk::now();
-          prof_feed += std::chrono::duration<double>(t1 - tp0).count();
+          prof_fetch += std::chrono::duration<double>(t1 - tp0).count();
           tp0 = t1;
         }
-        const int lrc = launch_tree(u);
-        if (profile) prof_launch += std::chrono::duration<double>(clk::now() - tp0).count();
-        if (lrc) return lrc;
-        if (un.m) continue;  // some tree of the unit is still growing
-        if (s->resident) resident_quit(s, u);
-        for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
-        if (!s->o.gibbs) {
-          if (int rc = finish_iteration(u, false)) return rc;
-          continue;
+        if (un.state == EVAL) {
+          for (int q = 0; q < un.m; ++q)
+            s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+          if (profile) {
+            const clk::time_point t1 = clk::now();
+            prof_feed += std::chrono::duration<double>(t1 - tp0).count();
+            tp0 = t1;
+          }
+          const int lrc = launch_tree(u);
+          if (profile) prof_launch += std::chrono::duration<double>(clk::now() - tp0).count();
+          if (lrc) return lrc;
+          if (un.m) continue;  // some tree of the unit is still growing
+          if (s->resident) resident_quit(s, u);
+          for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
+          if (!s->o.gibbs) {
+            if (int rc = finish_iteration(u, false)) return rc;
+            continue;
+          }
+          // binary Gibbs-Metropolis on [i_raw, ab_s_waner] of the unit's chains, then logp and gradient at the new
+          // states: queued back to back on the unit's stream
+          hipStream_t st = stream_of(u);
+          un.m = un.hi - un.lo;
+          for (int j = un.lo; j < un.hi; ++j) {
+            un.ids[(size_t)(j - un.lo)] = s->chains[(size_t)j];
+            un.who[(size_t)(j - un.lo)] = j;
+            std::memcpy(un.th.data() + (size_t)(j - un.lo) * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
+          }
+          if (int rc = enqueue_gibbs(c, un.m, un.ids.data(), un.th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + un.k),
+                                     (uint32_t)s->o.chain_offset, st, c->d_counts_chain + 2 * (size_t)un.lo,
+                                     c->d_work + c->n_slots + un.lo, nullptr))
+            return rc;
+          HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)un.lo, c->d_counts_chain + 2 * (size_t)un.lo,
+                                 (size_t)un.m * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          un.state = POST;
+          if (int rc = launch_eval(u)) return rc;
+        } else {  // POST: the sweep and the evaluation behind it are done (the counts landed before: same stream)
+          for (int q = 0; q < un.m; ++q)
+            s->ch[(size_t)un.who[(size_t)q]].nuts.set_point(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+          if (int rc = finish_iteration(u, true)) return rc;
         }
-        // binary Gibbs-Metropolis on [i_raw, ab_s_waner] of the unit's chains, then logp and gradient at the new
-        // states: queued back to back on the unit's stream
-        hipStream_t st = stream_of(u);
-        un.m = un.hi - un.lo;
-        for (int j = un.lo; j < un.hi; ++j) {
-          un.ids[(size_t)(j - un.lo)] = s->chains[(size_t)j];
-          un.who[(size_t)(j - un.lo)] = j;
-          std::memcpy(un.th.data() + (size_t)(j - un.lo) * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
-        }
-        if (int rc = enqueue_gibbs(c, un.m, un.ids.data(), un.th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + un.k),
-                                   (uint32_t)s->o.chain_offset, st, c->d_counts_chain + 2 * (size_t)un.lo,
-                                   c->d_work + c->n_slots + un.lo, nullptr))
-          return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)un.lo, c->d_counts_chain + 2 * (size_t)un.lo,
-                               (size_t)un.m * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        un.state = POST;
-        if (int rc = launch_eval(u)) return rc;
-      } else {  // POST: the sweep and the evaluation behind it are done (the counts landed before: same stream)
-        for (int q = 0; q < un.m; ++q)
-          s->ch[(size_t)un.who[(size_t)q]].nuts.set_point(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
-        if (int rc = finish_iteration(u, true)) return rc;
+      }
+      if (progressed && profile) busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
+      if (!any) break;
+      if (progressed) {
+        spins = 0;
+      } else if (++spins > 4000000) {
+        __atomic_fetch_add(&c->wait_fallbacks, (int64_t)1, __ATOMIC_RELAXED);  // no tag for tens of ms: synchronise the streams in flight (see abd_wait_fallbacks)
+        for (int u = tid; u < n_units; u += T)
+          if (units[(size_t)u].state != DONE) HIP_TRY(hipStreamSynchronize(stream_of(u)));
+        spins = 0;
+      } else {
+        __builtin_ia32_pause();
       }
     }
-    if (progressed && profile) busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
-    if (!any) break;
-    if (progressed) {
-      spins = 0;
-    } else if (++spins > 4000000) {
-      c->wait_fallbacks++;  // no tag for tens of ms: synchronise the streams in flight (see abd_wait_fallbacks)
-      for (int u = 0; u < n_units; ++u)
-        if (units[(size_t)u].state != DONE) HIP_TRY(hipStreamSynchronize(stream_of(u)));
-      spins = 0;
-    } else {
-      __builtin_ia32_pause();
+    if (profile) {
+      const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
+      std::fprintf(stderr, "abd sampler: thread %d of %d, %d units of %d chains in all, %ld results handled in %.3f s: host busy %.0f %% "
+                   "(%.2f us per result: %.2f assemble, %.2f NUTS, %.2f queueing the next evaluation)\n",
+                   tid, T, n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
+                   handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
+                   handled ? 1e6 * prof_launch / handled : 0.0);
+      if (g_launch_profile.on)
+        std::fprintf(stderr, "abd sampler: inside hipLaunchKernelGGL: %.2f us per evaluation launch (%ld), %.2f us per sum launch (%ld)\n",
+                     g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0, g_launch_profile.evals,
+                     g_launch_profile.sums ? 1e6 * g_launch_profile.sum_s / g_launch_profile.sums : 0.0, g_launch_profile.sums);
     }
+    return ABD_OK;
+  };
+  auto run_worker = [&](int tid) {
+    const int rc = worker(tid);
+    if (rc != ABD_OK) {
+      errors[(size_t)tid] = g_err;  // the message is thread-local: hand it to the calling thread
+      int expected = ABD_OK;
+      first_error.compare_exchange_strong(expected, rc);
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(run_worker, t);
+    run_worker(0);
+    for (auto& th : pool) th.join();
   }
-  if (profile) {
-    const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
-    std::fprintf(stderr, "abd sampler: %d units of %d chains, %ld results handled in %.3f s: host busy %.0f %% (%.2f us per result: "
-                 "%.2f assemble, %.2f NUTS, %.2f queueing the next evaluation)\n",
-                 n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
-                 handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
-                 handled ? 1e6 * prof_launch / handled : 0.0);
-    std::fprintf(stderr, "abd sampler: inside hipLaunchKernelGGL: %.2f us per evaluation launch (%ld), %.2f us per sum launch (%ld)\n",
-                 g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0, g_launch_profile.evals,
-                 g_launch_profile.sums ? 1e6 * g_launch_profile.sum_s / g_launch_profile.sums : 0.0, g_launch_profile.sums);
-    g_launch_profile.on = false;
+  g_launch_profile.on = false;
+  if (first_error.load() != ABD_OK) {
+    for (int t = 0; t < T; ++t)
+      if (!errors[(size_t)t].empty()) return fail(first_error.load(), "%s", errors[(size_t)t].c_str());
+    return fail(first_error.load(), "sampler thread failed");
   }
   // the context's stream continues behind everything the units queued
   for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;

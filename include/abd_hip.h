@@ -158,6 +158,9 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
  * re-evaluation are queued behind each other on its stream, and the host polls completion tags -- no unit waits
  * for another one's trees (as PyMC's one process per chain does not), and their launches overlap on the device.
  * What a unit computes depends only on the unit (fixed launch shape), never on the other units or on timing.
+ * Cohorts kept as observation lists are bound by the host's two kernel launches per evaluation, so their units are
+ * driven by up to four host threads inside abd_sampler_run (thread t the units t, t + 4, ...: what a thread touches is
+ * private to its units); dense cohorts are bound by the device and use the calling thread only.
  * Step size: dual averaging to `target_accept`; metric: diagonal, windowed running variance of the tuning draws
  * (abdpymc_amd/csrc/abd_nuts.hpp).
  * Iterations [0, tune) adapt; later ones are draws.  Randomness: one xoshiro256++ stream per chain keyed by

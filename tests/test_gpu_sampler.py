@@ -420,6 +420,64 @@ def test_a_chains_draws_do_not_depend_on_how_the_chains_are_grouped(test_td, mon
     assert len({tuple(th1[c, -1]) for c in range(5)}) == 5
 
 
+def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
+    """The units of an observation-list cohort are driven by up to four host threads (thread t the units t, t + 4, ...).
+    Whatever the number of threads and however the 6 chains are split into units, every chain's draws, statistics,
+    recorded Deterministics and final discrete state are the single-thread ones bit for bit; a dense cohort driven by
+    several threads (not the default there) is as reproducible as on one."""
+    from abdpymc_amd._native import Context
+    from abdpymc_amd.model import model
+
+    G, N, C = test_td.n_gaps, test_td.n_inds, 6
+
+    def run(threads, unit):
+        monkeypatch.setenv("ABD_SAMPLER_THREADS", str(threads))
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", str(unit))
+        m = model(test_td, splits=(14,), n_chains=C)
+        smp = m.ctx.sampler(np.arange(C), _start(m, C, seed=5), tune=20, seed=11, accumulate=True)
+        rec = dict(i=np.zeros((C, 30, G, N), np.int8), ab_s_mu=np.zeros((C, 30, G, N)))
+        th, st = smp.run_record(30, 0, **rec)
+        means = [smp.means(c)[1] for c in range(C)]
+        states = [m.ctx.get_discrete(c) for c in range(C)]
+        fb = m.ctx.wait_fallbacks
+        smp.close()
+        m.close()
+        return th, st, rec, means, states, fb
+
+    ref = run(1, 2)
+    for threads, unit in ((4, 1), (3, 2), (2, 1), (16, 1), (4, 8)):
+        got = run(threads, unit)
+        np.testing.assert_array_equal(got[0], ref[0])
+        for k in ref[1]:
+            np.testing.assert_array_equal(got[1][k], ref[1][k], err_msg=k)
+        np.testing.assert_array_equal(got[2]["i"], ref[2]["i"])
+        np.testing.assert_array_equal(got[2]["ab_s_mu"], ref[2]["ab_s_mu"])
+        for c in range(C):
+            np.testing.assert_array_equal(got[3][c], ref[3][c])
+            np.testing.assert_array_equal(got[4][c][0], ref[4][c][0])
+            np.testing.assert_array_equal(got[4][c][1], ref[4][c][1])
+        assert got[5] == 0
+
+    sc = synthetic.make_cohort(300, 40, seed=4)
+
+    def run_dense(threads):
+        monkeypatch.setenv("ABD_SAMPLER_THREADS", str(threads))
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", "1")
+        ctx = Context(40, 300, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=(17,), n_chains=4)
+        for c in range(4):
+            ctx.set_discrete(c, *synthetic.make_chain_state(300, 40, c))
+        smp = ctx.sampler(np.arange(4), np.stack([synthetic.make_thetas(40, 1, c)[0] for c in range(4)]), tune=10, seed=2)
+        th, st = smp.run(14)
+        smp.close()
+        ctx.close()
+        return th, st
+
+    th1, st1 = run_dense(1)
+    th4, st4 = run_dense(4)
+    np.testing.assert_array_equal(th1, th4)
+    np.testing.assert_array_equal(st1["gibbs_accepted"], st4["gibbs_accepted"])
+
+
 def test_units_on_a_dense_cohort_are_deterministic_and_record_like_a_twin_run():
     """Dense cohort (the dense evaluation kernel and the lane-per-proposal sweep), 3 chains as 3 units: two runs give the
     same bits; recording while running does not perturb the chains; every recorded `i` is the constrained `i_raw` of

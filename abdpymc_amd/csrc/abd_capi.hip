@@ -1848,16 +1848,17 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // that never wait for each other; a small cohort is bound by the host's ~6 us per launch, which a unit's chains share
   // (measured, tools/probe_nuts_rate.py: config 3 -- 8 chains 88 k evals/s with units of 1, 82 k with 4; 16 chains 92 k / 112 k;
   // default cohort, 16 chains -- 152 k with units of 1, 334 k with 4, 359 k with 8)
-  // With four host threads (observation lists, see below) the best split is four units -- one per thread and per
-  // hardware queue: default cohort, evaluations/s seen by NUTS with 4 / 8 / 16 chains 217 k / 339 k / 491 k against
-  // 166 k / 253 k / 300-370 k for the best split on one thread.
-  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(c->dense ? 2 : 1, std::min(8, (n + 3) / 4));
-  if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
-  s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
   // host threads that drive the units: one for dense cohorts (bound by the device), up to four for observation lists
   // (bound by the host's two launches per evaluation)
   s->threads = c->dense ? 1 : 4;
   if (const char* e = std::getenv("ABD_SAMPLER_THREADS")) s->threads = std::max(1, std::min(16, std::atoi(e)));
+  // With four host threads (observation lists) the best split is four units -- one per thread and per
+  // hardware queue: default cohort, evaluations/s seen by NUTS with 4 / 8 / 16 chains 217 k / 339 k / 491 k against
+  // 166 k / 253 k / 300-370 k for the best split on one thread.
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
+  if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
+  s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
+
   // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers
   // must not depend on it
   c->group_blocks = std::min(c->dense_blocks, c->n_cu);

@@ -371,3 +371,34 @@ def test_synchronous_batch_never_returns_a_stale_row():
         k = it & 1
         lp, g = ctx.logp_dlogp_batch(ids, thetas[k])
         assert np.array_equal(lp, want[k][0]) and np.array_equal(g, want[k][1]), it
+
+
+def test_stream_queue_probe_and_pipes():
+    """abd_stream_queues: every stream gets a queue number, numbers are 0 .. n_queues - 1 in order of first appearance,
+    a dense context rotates its stream-ordered launches over at most one stream per queue (and at most four), and the
+    stream-ordered results do not depend on that (they equal the synchronous ones to rounding)."""
+    from abdpymc_amd import synthetic
+    from abdpymc_amd._native import Context
+
+    sc = synthetic.make_cohort(640, 40, seed=2)
+    ctx = Context(40, 640, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=4)
+    q = ctx.stream_queues()
+    assert len(q) == 8 and q[0] == 0 and min(q) == 0
+    seen = []
+    for v in q:
+        if v not in seen:
+            assert v == len(seen)
+            seen.append(v)
+    assert 1 <= ctx.n_pipes <= min(4, len(seen))
+    for c in range(4):
+        ctx.set_discrete(c, *synthetic.make_chain_state(640, 40, c))
+    th = np.stack([synthetic.make_thetas(40, 1, c)[0] for c in range(4)])
+    for k in range(12):
+        ctx.enqueue(k, np.arange(4), th + 0.01 * k)
+    ctx.wait()
+    lp, g = ctx.fetch_many(np.arange(12), 4)
+    for k in range(12):
+        lp_s, g_s = ctx.logp_dlogp_batch(np.arange(4), th + 0.01 * k)
+        np.testing.assert_allclose(lp[k], lp_s, rtol=1e-12)
+        np.testing.assert_allclose(g[k], g_s, rtol=1e-9, atol=1e-9 * np.abs(g_s).max())
+    ctx.close()

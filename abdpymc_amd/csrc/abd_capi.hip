@@ -172,6 +172,7 @@ struct abd_ctx {
   unsigned long long* d_counts_chain = nullptr;  // [n_slots][2] counts of the sampler's per-chain sweeps ...
   unsigned long long* h_counts_chain = nullptr;  // ... and their pinned host copy
   bool gibbs_v1 = false;                   // ABD_GIBBS_V1=1: dense cohorts use the wave-per-proposal kernel too
+  int g2_refill_min = ABD_G2_REFILL_MIN, g2_tail_lanes = ABD_G2_TAIL_LANES, g2_tail_age = ABD_G2_TAIL_AGE;  // scheduler knobs of abd_gibbs_dense_kernel (ABD_G2_*)
   double* d_det = nullptr;                 // staging of abd_deterministics: mu_n, mu_s (G*N doubles each), i (G*N bytes)
   double* d_ring = nullptr;    // device-memory copy of the result ring: stream-ordered launches write here ...
   int ring_lo = 0, ring_hi = 0;  // ... and abd_wait flushes slots [ring_lo, ring_hi) to h_out with one small kernel
@@ -1155,6 +1156,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   if (const char* e = std::getenv("ABD_OBS_FUSED_SUM")) c->obs_fused = std::atoi(e) != 0;
   CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) c->g2_refill_min = std::max(1, std::min(64, std::atoi(e)));
+  if (const char* e = std::getenv("ABD_G2_TAIL_LANES")) c->g2_tail_lanes = std::max(0, std::min(64, std::atoi(e)));
+  if (const char* e = std::getenv("ABD_G2_TAIL_AGE")) c->g2_tail_age = std::max(0, std::atoi(e));
   c->results.resize((size_t)kResultSlots + c->n_sync_slots);
   CREATE_TRY(hipStreamSynchronize(c->stream));
   if (c->dense && c->n_pipes > 1) {
@@ -1358,12 +1362,9 @@ static int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double*
   }
   HIP_TRY(hipMemsetAsync(counts_dev, 0, (size_t)m * 2 * sizeof(unsigned long long), st));
   ga.work = work_dev;
-  ga.refill_min = ABD_G2_REFILL_MIN;
-  ga.tail_lanes = ABD_G2_TAIL_LANES;
-  ga.tail_age = ABD_G2_TAIL_AGE;
-  if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) ga.refill_min = std::max(1, std::min(64, std::atoi(e)));
-  if (const char* e = std::getenv("ABD_G2_TAIL_LANES")) ga.tail_lanes = std::max(0, std::min(64, std::atoi(e)));
-  if (const char* e = std::getenv("ABD_G2_TAIL_AGE")) ga.tail_age = std::max(0, std::atoi(e));
+  ga.refill_min = c->g2_refill_min;
+  ga.tail_lanes = c->g2_tail_lanes;
+  ga.tail_age = c->g2_tail_age;
   ga.stats = stats_dev;
   if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, 8 * sizeof(unsigned long long), st));
   const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;

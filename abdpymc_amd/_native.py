@@ -108,6 +108,7 @@ SYMBOLS = {
     "abd_wait": (C.c_int, [_P]),
     "abd_fetch": (C.c_int, [_P, C.c_int32, _D, _D]),
     "abd_fetch_many": (C.c_int, [_P, C.c_int32, _I32, _D, _D]),
+    "abd_logp_dlogp_many": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "abd_deterministics": (C.c_int, [_P, C.c_int32, _D, _I8, _D, _D]),
     "abd_sampler_create": (C.c_int, [_P, C.c_int32, _I32, _D, C.POINTER(_SamplerOpts), C.POINTER(_P)]),
     "abd_sampler_destroy": (None, [_P]),
@@ -414,6 +415,23 @@ class Context:
                 if a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
                     raise ValueError(f"output array must be C-contiguous float64 of shape {shape}")
         _check(self._lib, self._lib.abd_fetch_many(self._h, sl.size, _ptr(sl, C.c_int32), _ptr(lp, C.c_double), _ptr(g, C.c_double)))
+        return lp, g
+
+    def logp_dlogp_many(self, chains, thetas, out_lp=None, out_g=None):
+        """``thetas`` (K, n, 17): K independent evaluations of the same n chains, stream-ordered inside the library
+        (enqueue all, wait once, fetch) -> logp (K, n), grad (K, n, 17); ``out_lp`` / ``out_g`` to write into."""
+        ch = _as(chains, np.int32)
+        t = _as(thetas, np.float64)
+        if t.ndim != 3 or t.shape[1:] != (ch.size, N_THETA):
+            raise ValueError(f"thetas must have shape (K, {ch.size}, {N_THETA})")
+        K = t.shape[0]
+        lp = np.empty((K, ch.size)) if out_lp is None else out_lp
+        g = np.empty((K, ch.size, N_THETA)) if out_g is None else out_g
+        for a, shape in ((lp, (K, ch.size)), (g, (K, ch.size, N_THETA))):
+            if a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
+                raise ValueError(f"output array must be C-contiguous float64 of shape {shape}")
+        _check(self._lib, self._lib.abd_logp_dlogp_many(self._h, K, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double),
+                                                        _ptr(lp, C.c_double), _ptr(g, C.c_double)))
         return lp, g
 
     def deterministics(self, chain: int, theta):

@@ -1278,6 +1278,22 @@ int abd_fetch_many(abd_ctx* c, int32_t n_slots, const int32_t* slots, double* lo
   return ABD_OK;
 }
 
+int abd_logp_dlogp_many(abd_ctx* c, int32_t n_steps, int32_t n, const int32_t* chains, const double* theta, double* logp,
+                        double* grad) {
+  if (!c || !chains || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
+  if (n_steps < 0) return fail(ABD_ERR_ARG, "n_steps=%d is negative", n_steps);
+  const size_t per_step = (size_t)n * ABD_N_THETA;
+  for (int s0 = 0; s0 < n_steps; s0 += kResultSlots) {  // windows of the result ring
+    const int s1 = std::min(n_steps, s0 + kResultSlots);
+    for (int k = s0; k < s1; ++k)
+      if (int rc = enqueue_slot(c, k - s0, n, chains, theta + (size_t)k * per_step, grad != nullptr, true)) return rc;
+    if (int rc = abd_wait(c)) return rc;
+    for (int k = s0; k < s1; ++k)
+      if (int rc = fetch_slot(c, k - s0, logp + (size_t)k * n, grad ? grad + (size_t)k * per_step : nullptr)) return rc;
+  }
+  return ABD_OK;
+}
+
 int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
   if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
   if (int frc = flush_ring(c)) return frc;

@@ -143,6 +143,11 @@ int abd_wait(abd_ctx* ctx);
 int abd_fetch(abd_ctx* ctx, int32_t slot, double* logp, double* grad);
 /* abd_fetch for several slots in one call; outputs are concatenated in the order of `slots`. */
 int abd_fetch_many(abd_ctx* ctx, int32_t n_slots, const int32_t* slots, double* logp, double* grad);
+/* n_steps independent evaluations of the same chains in one call: theta is n_steps x n x 17, logp n_steps x n, grad
+ * n_steps x n x 17 (NULL: logp only).  The stream-ordered form end to end -- enqueue every step, wait once, fetch --
+ * for callers that hold many points at once (tempering, particle methods, a benchmark); result slots 0 .. are used. */
+int abd_logp_dlogp_many(abd_ctx* ctx, int32_t n_steps, int32_t n, const int32_t* chains, const double* theta,
+                        double* logp, double* grad);
 
 /* The three recorded Deterministics for chain slot `chain` at theta, each (G, N) row-major as PyMC
  * stores them (dims gap, ind).  Any output pointer may be NULL. */

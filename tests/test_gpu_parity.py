@@ -402,3 +402,28 @@ def test_stream_queue_probe_and_pipes():
         np.testing.assert_allclose(lp[k], lp_s, rtol=1e-12)
         np.testing.assert_allclose(g[k], g_s, rtol=1e-9, atol=1e-9 * np.abs(g_s).max())
     ctx.close()
+
+
+def test_many_evaluations_in_one_call():
+    """abd_logp_dlogp_many = enqueue every step, wait once, fetch: the same bits as doing that by hand, for more steps
+    than the result ring has slots too, and logp-only when no gradient is asked for."""
+    from abdpymc_amd import synthetic
+    from abdpymc_amd._native import Context
+
+    sc = synthetic.make_cohort(400, 30, seed=3)
+    ctx = Context(30, 400, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=2)
+    for c in range(2):
+        ctx.set_discrete(c, *synthetic.make_chain_state(400, 30, c))
+    K = ctx.n_result_slots + 37
+    th = np.stack([np.stack([synthetic.make_thetas(30, 1, 7 * k + c)[0] for c in range(2)]) for k in range(K)])
+    lp, g = ctx.logp_dlogp_many([0, 1], th)
+    assert lp.shape == (K, 2) and g.shape == (K, 2, 17)
+    for k in (0, 1, ctx.n_result_slots - 1, ctx.n_result_slots, K - 1):
+        ctx.enqueue(0, [0, 1], th[k])
+        ctx.wait()
+        lp1, g1 = ctx.fetch(0, 2)
+        np.testing.assert_array_equal(lp[k], lp1)
+        np.testing.assert_array_equal(g[k], g1)
+    with pytest.raises(ValueError):
+        ctx.logp_dlogp_many([0, 1], th[:, :1])
+    ctx.close()

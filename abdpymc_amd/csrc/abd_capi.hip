@@ -2019,7 +2019,9 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     std::vector<double> th, lp, gr;
   };
   std::vector<Unit> units((size_t)n_units);
-  const int T_all = std::max(1, std::min(s->threads, n_units));  // host threads (see below)
+  // host threads (see below): a power of two <= 8, so that units that share a HIP stream (u and u + 8) share their thread
+  int T_all = 1;
+  while (2 * T_all <= std::min({s->threads, n_units, (int)kMaxPipes})) T_all *= 2;
   if (s->unit_seq.size() != (size_t)n_units) {
     s->unit_seq.resize((size_t)n_units);
     for (int u = 0; u < n_units; ++u) s->unit_seq[(size_t)u] = (double)(u + 1) * 1099511627776.0;  // (u + 1) 2^40
@@ -2138,7 +2140,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   // where the host's two launches per evaluation (~7 us) are what bounds a single thread.
   // ABD_SAMPLER_PROFILE=1: how much of the wall time a host thread spends handling results and queueing launches.
   static const bool profile = std::getenv("ABD_SAMPLER_PROFILE") != nullptr;
-  const int T = std::max(1, std::min(s->threads, n_units));
+  const int T = T_all;
   g_launch_profile = LaunchProfile();
   g_launch_profile.on = profile && T == 1;
   using clk = std::chrono::steady_clock;

@@ -2015,6 +2015,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     int64_t staged = 0;  // draws staged on the device, not yet copied out
     int64_t flushed_to = 0;
     double tag = 0.0;
+    std::chrono::steady_clock::time_point t_queued;  // profile: when its last evaluation had been queued
     std::vector<int32_t> ids, who;
     std::vector<double> th, lp, gr;
   };
@@ -2037,6 +2038,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u), seqp);
     if (rc) return rc;
     un.tag = seqp ? *seqp : c->seq;
+    un.t_queued = std::chrono::steady_clock::now();
     return ABD_OK;
   };
   auto launch_tree = [&](int u) -> int {  // the next leapfrog of every tree of the unit that is still growing
@@ -2150,7 +2152,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     if (hipSetDevice(c->device) != hipSuccess) return fail(ABD_ERR_HIP, "hipSetDevice failed");
     const clk::time_point t_begin = clk::now();
     clk::time_point t_handle;
-    double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0;
+    double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0, prof_wait = 0.0;
     long handled = 0;
     for (long spins = 0;;) {
       bool any = false, progressed = false;
@@ -2177,6 +2179,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
           }
         }
         if (profile && !progressed) t_handle = clk::now();
+        if (profile) prof_wait += std::chrono::duration<double>(clk::now() - un.t_queued).count();
         progressed = true;
         ++handled;
         if (s->resident) s->res[(size_t)u].fails = 0;
@@ -2245,10 +2248,10 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     if (profile) {
       const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
       std::fprintf(stderr, "abd sampler: thread %d of %d, %d units of %d chains in all, %ld results handled in %.3f s: host busy %.0f %% "
-                   "(%.2f us per result: %.2f assemble, %.2f NUTS, %.2f queueing the next evaluation)\n",
+                   "(%.2f us per result: %.2f assemble, %.2f NUTS, %.2f queueing the next evaluation); evaluation queued -> result seen %.2f us\n",
                    tid, T, n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
                    handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
-                   handled ? 1e6 * prof_launch / handled : 0.0);
+                   handled ? 1e6 * prof_launch / handled : 0.0, handled ? 1e6 * prof_wait / handled : 0.0);
       if (g_launch_profile.on)
         std::fprintf(stderr, "abd sampler: inside hipLaunchKernelGGL: %.2f us per evaluation launch (%ld), %.2f us per sum launch (%ld)\n",
                      g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0, g_launch_profile.evals,

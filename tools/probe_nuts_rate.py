@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """logp+grad evaluations per second AS THE NATIVE SAMPLER SEES THEM (NUTS only, no sweep): leapfrogs of all chains
 per wall second inside abd_sampler_run.  usage: probe_nuts_rate.py [c3|c2|default] [chains] [iterations]
-ABD_SAMPLER_UNIT=B sets the chains per independent unit (default: 1 for large dense cohorts, 2-8 otherwise)."""
+ABD_SAMPLER_UNIT=B sets the chains per independent unit (default: 1 for large dense cohorts, 2-8 otherwise).
+The run ends with its slowest chain: with few iterations the rate understates what a long run sees (config 3, 4 chains:
+77 k evaluations/s over 40 iterations, 90 k over 1000)."""
 import os
 import sys
 import time

@@ -156,6 +156,11 @@ struct abd_ctx {
   // (write-through rows, one atomic round trip, coherent re-read) costs 4.4 us more than the queued second launch, and
   // the best rate the native sampler reaches on the reference's cohorts does not move
   bool obs_fused = false;
+  // A sampler unit's dense launch sums its own partial rows (abd_dense.hpp; ABD_DENSE_OWN_SUM=0: second launch).  Same
+  // bits; the result arrives 2-2.7 us later than from the pre-queued second launch, but the host spends 3.6 instead of
+  // 7.2 us per result: config 3, evaluations/s seen by NUTS 33.6 k -> 36.9 k (1 chain), 53 k -> 59 k (8), 77 k -> 88 k (16),
+  // unchanged with 4
+  bool dense_own_sum = true;
   unsigned int* d_fin_count = nullptr;  // [kMaxPipes][ABD_MAX_BATCH] zeroed counters of that sum
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
@@ -663,7 +668,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   const int buf = pp.pbuf;
   pp.pbuf ^= 1;
   a.partials = pp.partials[buf];
-  const bool fused_sum = lanes && c->obs_fused;  // the kernel sums its own partial rows (abd_obs.hpp): no second launch
+  // the kernel sums its own partial rows, no second launch: observation lanes (ABD_OBS_FUSED_SUM) / a sampler unit's dense launch (ABD_DENSE_OWN_SUM)
+  const bool fused_sum = (lanes && c->obs_fused) || (c->dense && !lanes && force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on));
   if (fused_sum) {
     a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
     a.fin_out = d_out_rows;
@@ -1154,6 +1160,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipMalloc(&c->d_fin_count, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
   CREATE_TRY(hipMemset(c->d_fin_count, 0, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
   if (const char* e = std::getenv("ABD_OBS_FUSED_SUM")) c->obs_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ABD_DENSE_OWN_SUM")) c->dense_own_sum = std::atoi(e) != 0;
   CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   if (const char* e = std::getenv("ABD_GIBBS_V1")) c->gibbs_v1 = std::atoi(e) != 0;
   if (const char* e = std::getenv("ABD_G2_REFILL_MIN")) c->g2_refill_min = std::max(1, std::min(64, std::atoi(e)));

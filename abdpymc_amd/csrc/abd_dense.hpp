@@ -407,7 +407,38 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
-    a.partials[((int64_t)(cbase + cc) * gridDim.x + blk) * ABD_NOUT + k] = v;  // rows in range order
+    double* dst = a.partials + ((int64_t)(cbase + cc) * gridDim.x + blk) * ABD_NOUT + k;  // rows in range order
+    if (a.fin_count)
+      __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another workgroup of THIS launch
+    else
+      *dst = v;
   }
   ABD_STAMP(8);
+  if (!a.fin_count) return;
+
+  // ---- own fixed-order sum (a sampler unit's launch, ABD_DENSE_OWN_SUM=1): the workgroup that counts in last for a chain
+  // sums that chain's partial rows itself instead of a second launch; hand-off and order as in abd_obs_kernel ----
+  int* flag = reinterpret_cast<int*>(red);  // the block reduction is done with: [CB] flags
+  __syncthreads();
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < CB) {
+      const unsigned int old = __hip_atomic_fetch_add(a.fin_count + cbase + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[lane] = old + 1u == gridDim.x ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  bool last[CB];  // workgroup-uniform; read before the sum's scratch may overwrite the flags
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) last[cc] = flag[cc] != 0;
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) {
+    if (last[cc]) {
+      finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
+                                         a.fin_out + (int64_t)(cbase + cc) * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.fin_tag);
+      if (tid == 0) __hip_atomic_store(a.fin_count + cbase + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
+  }
 }

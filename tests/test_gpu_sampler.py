@@ -478,6 +478,39 @@ def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
     np.testing.assert_array_equal(st1["gibbs_accepted"], st4["gibbs_accepted"])
 
 
+def test_dense_unit_launch_that_sums_its_own_partials_gives_the_same_draws(monkeypatch):
+    """A sampler unit's dense launch sums its own partial rows (last workgroup in, device-coherent re-read; the default)
+    or leaves that to a second launch (ABD_DENSE_OWN_SUM=0): same order of additions, so the same draws bit for bit,
+    with units of one and of two chains."""
+    from abdpymc_amd._native import Context
+
+    sc = synthetic.make_cohort(700, 130, seed=6)
+
+    def run(own, unit):
+        monkeypatch.setenv("ABD_DENSE_OWN_SUM", own)
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", unit)
+        ctx = Context(130, 700, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=(40, 90), n_chains=4)
+        for c in range(4):
+            ctx.set_discrete(c, *synthetic.make_chain_state(700, 130, c))
+        smp = ctx.sampler(np.arange(4), np.stack([synthetic.make_thetas(130, 1, c)[0] for c in range(4)]), tune=10, seed=8)
+        th, st = smp.run(16)
+        states = [ctx.get_discrete(c) for c in range(4)]
+        fb = ctx.wait_fallbacks
+        smp.close()
+        ctx.close()
+        return th, st, states, fb
+
+    for unit in ("1", "2"):
+        th0, st0, s0, _ = run("0", unit)
+        th1, st1, s1, fb = run("1", unit)
+        assert fb == 0
+        np.testing.assert_array_equal(th0, th1)
+        np.testing.assert_array_equal(st0["lp"], st1["lp"])
+        for (a, b), (c, d) in zip(s0, s1):
+            np.testing.assert_array_equal(a, c)
+            np.testing.assert_array_equal(b, d)
+
+
 def test_units_on_a_dense_cohort_are_deterministic_and_record_like_a_twin_run():
     """Dense cohort (the dense evaluation kernel and the lane-per-proposal sweep), 3 chains as 3 units: two runs give the
     same bits; recording while running does not perturb the chains; every recorded `i` is the constrained `i_raw` of

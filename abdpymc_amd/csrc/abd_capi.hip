@@ -1879,7 +1879,13 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // With four host threads (observation lists) the best split is four units -- one per thread and per
   // hardware queue: default cohort, evaluations/s seen by NUTS with 4 / 8 / 16 chains 217 k / 339 k / 491 k against
   // 166 k / 253 k / 300-370 k for the best split on one thread.
-  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? (n >= 16 ? 4 : 1) : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
+  // Large dense cohorts (one host thread): at most about four units -- the hardware queues -- of 1, 2, 4 or 8 chains, the
+  // sizes the dense kernel has a shape for (config 3, evaluations/s seen by NUTS over 150-300 iterations: 8 chains 79 k
+  // with units of 1, 112 k with 2; 12 chains 97 k / 88 k / 83 k with 2 / 3 / 4; 16 chains 91 k / 100 k with 2 / 4;
+  // 32 chains 100 k / 134 k with 4 / 8)
+  int dense_unit = 1;
+  while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
   if (const char* e = std::getenv("ABD_SAMPLER_UNIT")) s->unit = std::atoi(e);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
 

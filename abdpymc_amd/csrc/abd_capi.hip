@@ -93,6 +93,7 @@ struct ResultSlot {
   std::vector<int32_t> chains;
   std::vector<double> theta;  // n x 17
   std::vector<HostTerms> host;  // n: the host-side terms of every theta, computed when the evaluation is queued
+  double tag_first = 0.0;       // completion tag of the slot's first group of <= ABD_MAX_BATCH rows (group g: tag_first + g)
 };
 
 }  // namespace
@@ -172,6 +173,11 @@ struct abd_ctx {
   double* d_done = nullptr;
   double flush_tag = 0.0;      // tag of the flush in flight, 0 = none
   bool wait_poll = true;       // ABD_WAIT_POLL=0: abd_wait always synchronises the stream
+  // ABD_DIRECT_OUT: stream-ordered results go straight to the mapped host rows (as synchronous ones do) instead of a
+  // device ring that abd_wait copies out: no copy kernel behind the last launch, and a caller can take a slot's result
+  // as soon as its tag shows (abd_logp_dlogp_many assembles the early steps while the late ones still run)
+  bool direct_out = true;
+  std::vector<int> pending_slots;  // slots queued stream-ordered since the last abd_wait
   unsigned long long* d_counts = nullptr;  // [n_slots][2] Gibbs accepted / proposed
   unsigned int* d_work = nullptr;          // [2][n_slots] work queue heads of abd_gibbs_dense_kernel (second half: per-chain sweeps of the sampler)
   unsigned long long* d_counts_chain = nullptr;  // [n_slots][2] counts of the sampler's per-chain sweeps ...
@@ -788,6 +794,26 @@ int wait_rows(abd_ctx* c, int slot, int n, double tag, hipStream_t st = nullptr)
   return ABD_OK;
 }
 
+// Wait until every row of a stream-ordered slot carries its completion tag (direct_out: the rows are in mapped host memory).
+// Polls; after a second hands over to a synchronise of the context's stream (which every pipe has joined by then).
+int wait_slot(abd_ctx* c, int slot) {
+  const ResultSlot& r = c->results[slot];
+  volatile const double* rows = c->h_out + (size_t)slot * c->n_slots * ABD_NOUT;
+  const auto t_poll = std::chrono::steady_clock::now();
+  int k = r.n - 1;
+  for (long spin = 0;; ++spin) {
+    while (k >= 0 && rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] == r.tag_first + (double)(k / ABD_MAX_BATCH)) --k;
+    if (k < 0) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return ABD_OK;
+    }
+    __builtin_ia32_pause();
+    if ((spin & 4095) == 4095 && std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(1)) break;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ABD_OK;
+}
+
 int check_chains(abd_ctx* c, int n, const int32_t* chains) {
   if (!c) return fail(ABD_ERR_ARG, "ctx is NULL");
   if (n < 1 || n > c->n_slots) return fail(ABD_ERR_ARG, "n=%d outside [1, n_chain_slots=%d]", n, c->n_slots);
@@ -813,8 +839,10 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   for (int k = 0; k < n; ++k) r.host[(size_t)k] = prepare(theta + (size_t)k * ABD_N_THETA);
   // a synchronous call lets the finalize kernel write straight into mapped host memory (one PCIe write,
   // ~3 us inside the kernel); stream-ordered calls write device memory and are flushed together at abd_wait
-  double* rows = (deferred ? c->d_ring : c->d_out) + (size_t)slot * c->n_slots * ABD_NOUT;
-  if (deferred) {
+  double* rows = ((deferred && !c->direct_out) ? c->d_ring : c->d_out) + (size_t)slot * c->n_slots * ABD_NOUT;
+  r.tag_first = (seqp ? *seqp : c->seq) + 1.0;
+  if (deferred && c->direct_out) c->pending_slots.push_back(slot);
+  if (deferred && !c->direct_out) {
     if (c->ring_lo == c->ring_hi) {
       c->ring_lo = slot;
       c->ring_hi = slot + 1;
@@ -1153,6 +1181,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   std::memset(c->h_done, 0, 64);
   CREATE_TRY(hipHostGetDevicePointer((void**)&c->d_done, c->h_done, 0));
   if (const char* e = std::getenv("ABD_WAIT_POLL")) c->wait_poll = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ABD_DIRECT_OUT")) c->direct_out = std::atoi(e) != 0;
   CREATE_TRY(hipMalloc(&c->d_ring, out_bytes));
   CREATE_TRY(hipMalloc(&c->d_counts, ((size_t)c->n_slots * 2 + 8) * sizeof(unsigned long long)));  // + 8 development counters
   CREATE_TRY(hipMalloc(&c->d_work, (size_t)2 * c->n_slots * sizeof(unsigned int)));
@@ -1247,6 +1276,14 @@ int abd_wait(abd_ctx* c) {
   c->flush_tag = 0.0;  // only a flush queued by THIS call may stand in for the synchronise
   int rc = flush_ring(c);
   if (rc) return rc;
+  if (c->direct_out && !c->pending_slots.empty() && c->wait_poll) {
+    // every stream-ordered slot's rows carry a tag: the newest slots land last, so poll backwards and stop early
+    for (size_t q = c->pending_slots.size(); q-- > 0;)
+      if (int wrc = wait_slot(c, c->pending_slots[q])) return wrc;
+    c->pending_slots.clear();
+    return ABD_OK;
+  }
+  c->pending_slots.clear();
   if (c->flush_tag != 0.0) {  // the flush raises a tag in mapped memory when it is done
     const double tag = c->flush_tag;
     c->flush_tag = 0.0;
@@ -1294,6 +1331,19 @@ int abd_logp_dlogp_many(abd_ctx* c, int32_t n_steps, int32_t n, const int32_t* c
     const int s1 = std::min(n_steps, s0 + kResultSlots);
     for (int k = s0; k < s1; ++k)
       if (int rc = enqueue_slot(c, k - s0, n, chains, theta + (size_t)k * per_step, grad != nullptr, true)) return rc;
+    if (c->direct_out && c->wait_poll) {
+      // the results land in mapped host memory slot by slot: queue the pending sums and the joins, then take every step's
+      // result as soon as its tag shows -- the host-side assembly of the early steps overlaps the late steps' kernels
+      HIP_TRY(hipSetDevice(c->device));
+      c->flush_tag = 0.0;
+      if (int rc = flush_ring(c)) return rc;
+      for (int k = s0; k < s1; ++k) {
+        if (int rc = wait_slot(c, k - s0)) return rc;
+        if (int rc = fetch_slot(c, k - s0, logp + (size_t)k * n, grad ? grad + (size_t)k * per_step : nullptr)) return rc;
+      }
+      c->pending_slots.clear();
+      continue;
+    }
     if (int rc = abd_wait(c)) return rc;
     for (int k = s0; k < s1; ++k)
       if (int rc = fetch_slot(c, k - s0, logp + (size_t)k * n, grad ? grad + (size_t)k * per_step : nullptr)) return rc;

@@ -196,6 +196,7 @@ struct abd_ctx {
   bool win_open = false;
   int64_t win_launches = 0;  // launches inside the windows collected so far
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<hipEvent_t> win_end;  // timing 2: [window][kMaxPipes] end of each pipe's work in the window (the window ends with the latest)
   size_t ev_used = 0;
   double ev_total_ms = 0.0;
   int64_t ev_count = 0;
@@ -743,12 +744,25 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
 }
 
 int flush_ring(abd_ctx* c) {
-  if (int prc = flush_pending(c)) return prc;
-  if (c->win_open) {  // timing 2: the window closes once every pipe's last launch and sum have joined the context's stream
-    HIP_TRY(hipEventRecord(c->ev_pool[c->ev_used].second, c->stream));
+  if (c->win_open) {
+    // timing 2: the window ends when the last pipe has finished its last launch and that launch's sum -- what a caller
+    // that polls the completion tags waits for.  One end event per pipe, behind its pending sum and BEFORE the joins
+    // (the joins' barrier packets on the context's stream come after the results and are not part of the work).
+    const size_t w = c->ev_used;
+    if (c->win_end.size() < (w + 1) * kMaxPipes) {
+      const size_t old_n = c->win_end.size();
+      c->win_end.resize((w + 1) * kMaxPipes, nullptr);
+      for (size_t k = old_n; k < c->win_end.size(); ++k) HIP_TRY(hipEventCreate(&c->win_end[k]));
+    }
+    for (int pi = 0; pi < c->n_streams; ++pi) {
+      if (!c->pipe[pi].st) continue;
+      if (int prc = flush_pipe(c, pi)) return prc;
+      HIP_TRY(hipEventRecord(c->win_end[w * kMaxPipes + pi], c->pipe[pi].st));
+    }
     c->ev_used++;
     c->win_open = false;
   }
+  if (int prc = flush_pending(c)) return prc;
   if (c->ring_lo < c->ring_hi) {
     const size_t row = (size_t)c->n_slots * ABD_NOUT;
     const int64_t count = (int64_t)(c->ring_hi - c->ring_lo) * row;
@@ -996,6 +1010,8 @@ void free_ctx(abd_ctx* c) {
   if (c->d_fin_count) (void)hipFree(c->d_fin_count);
   if (c->h_counts_chain) (void)hipHostFree(c->h_counts_chain);
   if (c->d_det) (void)hipFree(c->d_det);
+  for (auto& e : c->win_end)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev_pool) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
@@ -1584,7 +1600,15 @@ int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t res
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (size_t k = 0; k < c->ev_used; ++k) {
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
+    if (c->timing == 2) {  // window: first launch's start .. the latest pipe's end
+      for (int pi = 0; pi < c->n_streams; ++pi) {
+        if (!c->pipe[pi].st || (k + 1) * kMaxPipes > c->win_end.size()) continue;
+        float m = 0.f;
+        if (hipEventElapsedTime(&m, c->ev_pool[k].first, c->win_end[k * kMaxPipes + pi]) == hipSuccess) ms = std::max(ms, m);
+      }
+    } else {
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
+    }
     c->ev_total_ms += ms;
     if (c->timing != 2) c->ev_count++;
   }

@@ -22,15 +22,15 @@ def _run(args, env=None, timeout=900):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _run(["--steps", "40", "--warmup", "3", "--cpu-seconds", "4"])
+    d = _run(["--steps", "20", "--warmup", "5", "--cpu-seconds", "4"])  # the steps / warm-up the driver runs it with
     assert d["metric"] == "logp+grad evals/sec" and d["unit"] == "evals/s" and d["higher_is_better"] is True
-    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["config"]["workload"].startswith("synthetic 10000 ind x 200 gaps") and "model" not in d["config"]
-    assert d["value"] > 1e4 and abs(d["value"] - 40 * 4 / (d["ms_per_step"] * 40 / 1e3)) < 1e-3 * d["value"]
+    assert d["value"] > 1e4 and abs(d["value"] - 20 * 4 / (d["ms_per_step"] * 20 / 1e3)) < 1e-3 * d["value"]
     # the K-step region is repeated and the median reported
     assert d["repeats"] >= 3 and d["region_ms"]["min"] <= d["region_ms"]["median"] <= d["region_ms"]["max"]
-    assert abs(d["region_ms"]["median"] - d["ms_per_step"] * 40) < 1e-3 * d["region_ms"]["median"]
+    assert abs(d["region_ms"]["median"] - d["ms_per_step"] * 20) < 1e-3 * d["region_ms"]["median"]
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
@@ -38,10 +38,10 @@ def test_bench_line_has_the_contract_fields():
     assert ro["traffic"] is None or ro["traffic"] >= 0.9 * ro["algorithmic_bytes_per_launch"]
     # the entry that carries frac describes the launch shape that was timed: its device time per launch cannot
     # exceed the host's time per step (which adds the wait and the fetch)
-    assert ro["kernel_us"] <= d["ms_per_step"] * 1e3 * 1.02, (ro["kernel_us"], d["ms_per_step"])
-    assert ro["launches"] % 40 == 0 and ro["launches"] >= 120
+    assert ro["kernel_us"] <= d["ms_per_step"] * 1e3 * 1.01, (ro["kernel_us"], d["ms_per_step"])
+    assert ro["launches"] % 20 == 0 and ro["launches"] >= 60
     iso = ro["isolated"]
-    assert iso["kernel_us"] > 0 and abs(iso["frac"] - iso["achieved"] / 8000.0) < 1e-3 and iso["launches"] % 40 == 0
+    assert iso["kernel_us"] > 0 and abs(iso["frac"] - iso["achieved"] / 8000.0) < 1e-3 and iso["launches"] % 20 == 0
     if ro["valu"] is not None:
         assert ro["valu"]["peak"] == 78.6 and 0 < ro["valu"]["frac"] < 1.2
     cb = d["cpu_baseline"]

@@ -182,21 +182,36 @@ def main():
         gather_samples(np.zeros((K, C, 18)), dist, device=comm_dev)
 
     # ---- timed: EXACTLY K steps per region, R regions ----
+    # The device time of every timed region is taken in the SAME region: HIP events on the streams the kernels run on
+    # (abd_kernel_timing mode 2: a start event in front of the region's first launch, an end event per stream behind its
+    # last launch and that launch's sum).  They are read back after the region's clock has stopped.
+    ctx.kernel_timing(2)
+    ctx.kernel_time(reset=True)
+    w_per_launch, w_n = [], 0
+
     def region():
         # barrier, W steps so the part is under load again (a barrier idles it; a few ms of idling cost ~2.5 ms of
         # ramp-up, tools/probe_idle_penalty.py), then the barrier + sync that opens the region
+        nonlocal w_n
         if dist is not None:
             barrier()
             run_steps(0, W)
         barrier()
+        ctx.kernel_time(reset=True)
         t0 = time.perf_counter()
-        run_steps(W, W + K, lp_all, g_all)  # ends with a device sync (abd_wait) and the fetch
-        return time.perf_counter() - t0
+        run_steps(W, W + K, lp_all, g_all)  # every step's result waited for and fetched
+        dt = time.perf_counter() - t0
+        ms_r, n_r = ctx.kernel_time(reset=True)
+        w_per_launch.append(ms_r / max(n_r, 1))
+        w_n += n_r
+        return dt
 
     first = float(all_max([region()])[0])
     n_rep = int(min(args.max_repeats, max(3, np.ceil(args.min_seconds / max(first, 1e-9)))))
+    w_per_launch, w_n = [], 0
     times = all_max([region() for _ in range(n_rep)])
     elapsed = float(np.median(times))
+    ctx.kernel_timing(0)
     if not np.all(np.isfinite(lp_all)):
         raise SystemExit("non-finite logp in the timed region")
 
@@ -223,18 +238,10 @@ def main():
         sync_rates.append(ks * C / (time.perf_counter() - t1))
     sync_rate = float(np.median(sync_rates))
 
-    # ---- device time of the timed launch shape: HIP events around every window of K stream-ordered launches ----
-    warm(0.02)
-    ctx.kernel_timing(2)
-    ctx.kernel_time(reset=True)
-    w_per_launch, w_n = [], 0
-    for _ in range(int(min(n_rep, 60))):
-        run_steps(W, W + K)
-        ms_r, n_r = ctx.kernel_time(reset=True)
-        w_per_launch.append(ms_r / max(n_r, 1))
-        w_n += n_r
     # ---- the isolated kernel: HIP events around every launch, one stream, full grid ----
+    warm(0.02)
     ctx.kernel_timing(1)
+    ctx.kernel_time(reset=True)
     k_per_launch, k_n = [], 0
     for _ in range(int(min(n_rep, 10))):
         run_steps(W, W + K)
@@ -274,7 +281,7 @@ def main():
         traffic=pipe_prof.get("hbm_bytes_per_launch"), kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel",
         kernel_us=round(w_avg_s * 1e6, 3), launches=int(w_n),
         launch_shape=f"stream-ordered, as timed: launches rotate over {ctx.n_pipes} HIP streams on different hardware queues, "
-                     "1 workgroup per CU each; device time from HIP events around each window of K launches / K",
+                     "1 workgroup per CU each; device time from HIP events around the K launches of every timed region / K (median)",
         algorithmic_bytes_per_launch=int(alg_bytes), survey_bytes_per_launch=int(survey_bytes), evals_per_launch=C,
         isolated=dict(kernel_us=round(k_avg_s * 1e6, 3), achieved=round(iso_achieved, 2), frac=round(iso_achieved / HBM_PEAK_GBS, 4),
                       launches=int(k_n), traffic=prof.get("hbm_bytes_per_launch"),

@@ -197,6 +197,7 @@ struct abd_ctx {
   int64_t win_launches = 0;  // launches inside the windows collected so far
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<hipEvent_t> win_end;  // timing 2: [window][kMaxPipes] end of each pipe's work in the window (the window ends with the latest)
+  std::vector<uint32_t> win_mask;   // ... and which pipes had work in it
   size_t ev_used = 0;
   double ev_total_ms = 0.0;
   int64_t ev_count = 0;
@@ -754,10 +755,13 @@ int flush_ring(abd_ctx* c) {
       c->win_end.resize((w + 1) * kMaxPipes, nullptr);
       for (size_t k = old_n; k < c->win_end.size(); ++k) HIP_TRY(hipEventCreate(&c->win_end[k]));
     }
+    if (c->win_mask.size() < w + 1) c->win_mask.resize(w + 1, 0u);
+    c->win_mask[w] = 0u;
     for (int pi = 0; pi < c->n_streams; ++pi) {
-      if (!c->pipe[pi].st) continue;
+      if (!c->pipe[pi].st || !(pi == 0 || c->pipe[pi].busy || c->pipe[pi].on)) continue;  // no work of this window on it
       if (int prc = flush_pipe(c, pi)) return prc;
       HIP_TRY(hipEventRecord(c->win_end[w * kMaxPipes + pi], c->pipe[pi].st));
+      c->win_mask[w] |= 1u << pi;
     }
     c->ev_used++;
     c->win_open = false;
@@ -1602,7 +1606,7 @@ int abd_kernel_time(abd_ctx* c, double* total_ms, int64_t* launches, int32_t res
     float ms = 0.f;
     if (c->timing == 2) {  // window: first launch's start .. the latest pipe's end
       for (int pi = 0; pi < c->n_streams; ++pi) {
-        if (!c->pipe[pi].st || (k + 1) * kMaxPipes > c->win_end.size()) continue;
+        if (!c->pipe[pi].st || (k + 1) * kMaxPipes > c->win_end.size() || k >= c->win_mask.size() || !(c->win_mask[k] >> pi & 1u)) continue;
         float m = 0.f;
         if (hipEventElapsedTime(&m, c->ev_pool[k].first, c->win_end[k * kMaxPipes + pi]) == hipSuccess) ms = std::max(ms, m);
       }

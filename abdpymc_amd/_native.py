@@ -125,7 +125,6 @@ SYMBOLS = {
     "abd_set_launch_config": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "abd_algorithmic_bytes": (C.c_int64, [_P, C.c_int32]),
     "abd_wait_fallbacks": (C.c_int64, [_P]),
-    "abd_resident_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "abd_stream_queues": (C.c_int, [_P, _I32, C.c_int32]),
     "abd_n_pipes": (C.c_int, [_P]),
     "abd_is_dense": (C.c_int, [_P]),
@@ -175,11 +174,22 @@ def _tptr(arr, ctype):
 
 
 def _ptr(arr, ctype=None):
-    """Address of a C-contiguous array's data (the array must stay referenced by the caller for the duration of the call)."""
+    """Address of a C-contiguous array's data (the array must stay referenced by the caller for the duration of the call).
+    INPUT arguments only (the library reads through it): a read-only array is fine here."""
     try:
         return C.addressof(C.c_char.from_buffer(arr))  # 0.4 us; needs a writable, non-empty buffer
     except (TypeError, ValueError, BufferError):
         return arr.ctypes.data
+
+
+def _out(arr, dtype, shape=None, name="output array"):
+    """Address of an array the LIBRARY WRITES: it must be writeable, C-contiguous, of the exact dtype (ctypes sees only an
+    address, so nothing else would catch a read-only memmap or a float32 buffer before the library writes through it)."""
+    if not isinstance(arr, np.ndarray) or arr.dtype != dtype or not arr.flags.c_contiguous or not arr.flags.writeable:
+        raise ValueError(f"{name} must be a writeable C-contiguous {np.dtype(dtype).name} ndarray")
+    if shape is not None and arr.shape != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {arr.shape}")
+    return _ptr(arr)
 
 
 class Context:
@@ -291,13 +301,6 @@ class Context:
     def wait_fallbacks(self) -> int:
         """Synchronous calls that had to fall back from the polled completion tag to a stream synchronise (expect 0)."""
         return int(self._lib.abd_wait_fallbacks(self._h))
-
-    @property
-    def resident_stats(self) -> dict:
-        """Resident evaluation kernels of the native sampler: launches, evaluations served, relaunches after a time-out."""
-        a, b, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        _check(self._lib, self._lib.abd_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(r)))
-        return {"launches": a.value, "commands": b.value, "restarts": r.value}
 
     def stream_queues(self):
         """Hardware queue of each of the context's 8 HIP streams (streams with the same number serialise their kernels)."""
@@ -421,11 +424,9 @@ class Context:
         sl = _as(slots, np.int32)
         lp = np.empty((sl.size, n_per_slot)) if out_lp is None else out_lp
         g = np.empty((sl.size, n_per_slot, N_THETA)) if out_g is None else out_g
-        if out_lp is not None or out_g is not None:
-            for a, shape in ((lp, (sl.size, n_per_slot)), (g, (sl.size, n_per_slot, N_THETA))):
-                if a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
-                    raise ValueError(f"output array must be C-contiguous float64 of shape {shape}")
-        _check(self._lib, self._lib.abd_fetch_many(self._h, sl.size, _ptr(sl, C.c_int32), _ptr(lp, C.c_double), _ptr(g, C.c_double)))
+        _check(self._lib, self._lib.abd_fetch_many(self._h, sl.size, _ptr(sl, C.c_int32),
+                                                   _out(lp, np.float64, (sl.size, n_per_slot), "out_lp"),
+                                                   _out(g, np.float64, (sl.size, n_per_slot, N_THETA), "out_g")))
         return lp, g
 
     def logp_dlogp_many(self, chains, thetas, out_lp=None, out_g=None):
@@ -438,11 +439,9 @@ class Context:
         K = t.shape[0]
         lp = np.empty((K, ch.size)) if out_lp is None else out_lp
         g = np.empty((K, ch.size, N_THETA)) if out_g is None else out_g
-        for a, shape in ((lp, (K, ch.size)), (g, (K, ch.size, N_THETA))):
-            if a.dtype != np.float64 or not a.flags.c_contiguous or a.shape != shape:
-                raise ValueError(f"output array must be C-contiguous float64 of shape {shape}")
         _check(self._lib, self._lib.abd_logp_dlogp_many(self._h, K, ch.size, _ptr(ch, C.c_int32), _ptr(t, C.c_double),
-                                                        _ptr(lp, C.c_double), _ptr(g, C.c_double)))
+                                                        _out(lp, np.float64, (K, ch.size), "out_lp"),
+                                                        _out(g, np.float64, (K, ch.size, N_THETA), "out_g")))
         return lp, g
 
     def deterministics(self, chain: int, theta):
@@ -590,8 +589,8 @@ class NativeSampler:
                                     ("ab_s_mu", ab_s_mu, np.float64, (G, N))):
             if arr is None:
                 continue
-            if arr.dtype != dt or not arr.flags.c_contiguous or arr.shape[0] != self.n or arr.shape[2:] != tail:
-                raise ValueError(f"{name}: need a C-contiguous {np.dtype(dt).name} array of shape (n, capacity) + {tail}")
+            if arr.dtype != dt or not arr.flags.c_contiguous or not arr.flags.writeable or arr.shape[0] != self.n or arr.shape[2:] != tail:
+                raise ValueError(f"{name}: need a writeable C-contiguous {np.dtype(dt).name} array of shape (n, capacity) + {tail}")
             if cap is not None and arr.shape[1] != cap:
                 raise ValueError("record arrays differ in capacity")
             cap = arr.shape[1]

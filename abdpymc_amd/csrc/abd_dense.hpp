@@ -21,7 +21,8 @@
 //   * gap rows are addressed as scalar row base + a constant per-lane offset (no vector address arithmetic)
 #pragma once
 
-#define ABD_EXP2_TAB 1024  // entries of the 2^(j/1024) table (8 KB of LDS per workgroup)
+#include "abd_device.hpp"
+
 
 // bits [g0, g0 + 32) of the packed row, moved to bit 0 (g0 wave-uniform; bits past the row's end read as zero).
 // Every word is visited with a compile-time index (a runtime-indexed register array would go to scratch); the
@@ -63,46 +64,6 @@ __device__ __forceinline__ YX<float> load_yx<float>(const __amdgpu_buffer_rsrc_t
   return r;
 }
 
-// the double whose high word is `hi` and whose low word is `zero` (a register that holds 0; 0.0 and 1.0 are such
-// doubles).  Each stream of such doubles gets its own zero register (zero_vgpr), so that the register pair is
-// {that register, hi} and the high word is computed in place -- with a shared literal 0 the compiler copies it
-// into the low half of every new pair, one v_mov_b32 per double per gap.
-__device__ __forceinline__ double hi_to_double(uint32_t hi, uint32_t zero) { return __hiloint2double((int)hi, (int)zero); }
-__device__ __forceinline__ uint32_t zero_vgpr() {
-  uint32_t z = 0;
-  asm volatile("" : "+v"(z));
-  return z;
-}
-// rho * x + y with a scalar rho as ONE three-address v_fma_f64 (left to itself the compiler picks the two-address
-// v_fmac_f64 for the loop-carried recurrences and pays a v_mov_b64 to keep the old value)
-__device__ __forceinline__ double fma_s(double rho_sgpr, double x, double y) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(rho_sgpr), "v"(x), "v"(y));
-  return r;
-}
-__device__ __forceinline__ double fma_v(double rho_vgpr, double x, double y) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(rho_vgpr), "v"(x), "v"(y));
-  return r;
-}
-
-// 1 + 2^(t1024 / 1024).  kf = rint(t1024), f = t1024 - kf exact; v_cvt_i32_f64 saturates, so any finite t1024 gives
-// a finite result (the exponent is clamped to [-1022, 510]: 2^510 keeps the product of the two antigens' terms
-// finite, below 2^-1022 the term is 1 anyway); NaN stays NaN.
-__device__ __forceinline__ double one_plus_exp2_tab(double t1024, const double* tab /* LDS */) {
-  const double kf = __builtin_rint(t1024);
-  const double f = t1024 - kf;
-  int k;
-  asm("v_cvt_i32_f64 %0, %1" : "=v"(k) : "v"(kf));  // saturating; a C++ cast of an out-of-range double is undefined
-  const double T = tab[k & (ABD_EXP2_TAB - 1)];
-  const int e = min(max(k >> 10, -1022), 510);  // v_med3_i32
-  const double Ts = __hiloint2double(__double2hiint(T) + (e << 20), __double2loint(T));  // T 2^e: v_lshl_add_u32
-  double p = fma(0x1.c6b08d910ecbdp-35, f, 0x1.ebfbe033445b4p-23);  // tools/exp2_table.py 1024 3
-  p = fma(p, f, 0x1.62e42fefa39efp-11);
-  p = fma(p, f, 1.0);
-  return fma(Ts, p, 1.0);
-}
-static_assert(ABD_EXP2_TAB == 1024, "one_plus_exp2_tab: k >> 10 and the polynomial assume 1024 entries");
 
 // Both antigens of one cell at once: the two reciprocals 1/(1+e_n), 1/(1+e_s) come from ONE v_rcp_f64 (quarter
 // rate) of the product -- 1/A = B/(AB), 1/B = A/(AB).  c_n = b_n log2(e) 1024, c_s likewise (wave-uniform).

@@ -20,76 +20,7 @@
 // be compared bit for bit.
 #pragma once
 
-struct Philox4 {
-  uint32_t w[4];
-};
-
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                          uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  Philox4 o;
-  o.w[0] = c0;
-  o.w[1] = c1;
-  o.w[2] = c2;
-  o.w[3] = c3;
-  return o;
-}
-
-#define ABD_TRANSIT_P_U32 3435973836u  // floor(0.8 * 2^32): propose iff word 1 < this   (transit_p = 0.8)
-#define ABD_GIBBS_WAVE_LDS 3904        // per wave: keys u32[260] + order u16[260] + transit u8[260] (padded to 264) + log u f64[260]
-
-struct GibbsArgs {
-  EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)
-  uint32_t seed_lo, seed_hi, sweep;
-  uint32_t ind_offset;  // added to the individual's index in the Philox counter (cohort sharded by individual)
-  uint32_t stream[ABD_MAX_BATCH_K];  // third counter word of each chain: its slot id (+ the caller's offset)
-  double theta0[ABD_MAX_BATCH_K];  // log p - log(1 - p)             = p_logodds__
-  double theta7[ABD_MAX_BATCH_K];  // log p_waner - log(1 - p_waner) = ab_s_p_waner_logodds__
-  double is2_n[ABD_MAX_BATCH_K];   // 1 / sigma_n^2
-  double is2_s[ABD_MAX_BATCH_K];
-  unsigned long long* counts;      // [n_chains][2]: accepted, proposed (integer atomics: order-free)
-  unsigned int* work;              // [n_chains]: next individual of each chain (abd_gibbs_dense_kernel's work queue), zeroed per launch
-  unsigned long long* stats;       // nullptr, or 8 development counters of abd_gibbs_dense_kernel (ABD_GIBBS_STATS=1)
-  int32_t refill_min, tail_lanes, tail_age;  // scheduler knobs of abd_gibbs_dense_kernel (abd_gibbs2.hpp)
-};
-
-__device__ __forceinline__ double readfirstlane_f64(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-// ---- wave sum without LDS traffic: four DPP steps inside each row of 16 lanes, then the four row totals ----
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double wave_sum_uniform(double v) {  // the same value in every lane (wave-uniform)
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
+#include "abd_device.hpp"
 
 // This lane's share of -1/2 sum (q / sigma)^2 over the individual's observations for the given masks (terms
 // that do not depend on the discrete state are left out: they cancel in every difference).
@@ -436,10 +367,3 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   }
 }
 
-// packed words [nt][N] -> (G, N) gap-major int8, for reading a chain's i_raw back
-__global__ __launch_bounds__(256) void abd_unpack_bits_kernel(const uint64_t* __restrict__ src, int8_t* __restrict__ dst,
-                                                              int G, int N) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
-  if (j < N && g < G) dst[(int64_t)g * N + j] = (int8_t)((src[(int64_t)(g >> 6) * N + j] >> (g & 63)) & 1ull);
-}

@@ -28,13 +28,12 @@
 // suffix sums of the current terms, log u per dim, the proposal list and one result byte per proposal.
 #pragma once
 
+#include "abd_gibbs.hpp"
+
 #define ABD_G2_PENDING 0
 #define ABD_G2_REJECT 1
 #define ABD_G2_ACCEPT 2
 #define ABD_G2_COMPLEX 3
-#define ABD_G2_REFILL_MIN 16         // idle lanes that trigger a refill (a refill costs ~2-3 walk steps)
-#define ABD_G2_TAIL_LANES 8          // walkers left when the whole wave starts finishing them one at a time ...
-#define ABD_G2_TAIL_AGE 6            // ... those that have survived this many gaps
 #define ABD_G2_ITER_CAP (1 << 20)    // hard bound on scheduler iterations per individual (never reached: see the loop)
 
 #define ABD_G2_MAX_WAVES 12  // waves of a workgroup (= of a CU: one workgroup per CU, three waves per SIMD, <= 168 registers)

@@ -15,6 +15,8 @@
 // Included by abd_kernels.hpp.
 #pragma once
 
+#include "abd_device.hpp"
+
 // exposures of the set bits of `m` (word t) at or before gap g: sum of tab[g - pos + 1]
 __device__ __forceinline__ void add_bits(uint64_t m, int t, int g, const double2_t* tab, double& u, double& d) {
   const int rel = g - t * 64;
@@ -165,32 +167,6 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
       for (int w = 0; w < ABD_WAVES_PER_BLOCK; ++w) v += red[w * 8 + src];
     }
     double* row = a.partials + ((int64_t)blockIdx.y * gridDim.x + b) * ABD_NOUT;
-    if (a.fin_count)
-      __hip_atomic_store(row + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: see below
-    else
-      row[tid] = v;
-  }
-  if (!a.fin_count) return;  // the fixed-order sum follows as its own launch (abd_finalize_kernel)
-
-  // ---- fused fixed-order sum: the workgroup of this chain that counts in last does it ----
-  // Every workgroup's row is in memory (write-through stores, waited for) before it counts itself in with one
-  // device-scope atomic; the last one in reads all rows with device-coherent loads, in finalize_chain's order (same
-  // bits as the separate launch), writes the chain's 16 doubles + tag, and leaves the counter at zero for the next
-  // launch on this stream.  Saves the second launch of every evaluation: ~3.5 us of host time per result, which is
-  // what bounds the native sampler on the reference's cohorts.
-  int* flag = reinterpret_cast<int*>(red + ABD_WAVES_PER_BLOCK * 8);
-  if (wave == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      const unsigned int old = __hip_atomic_fetch_add(a.fin_count + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = old + 1u == gridDim.x ? 1 : 0;
-    }
-  }
-  __syncthreads();
-  if (flag[0]) {
-    finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)blockIdx.y * gridDim.x * ABD_NOUT, (int)gridDim.x,
-                                       a.fin_out + (int64_t)blockIdx.y * ABD_NOUT, reinterpret_cast<double*>(smem + abd_obs_lds_head(G)), tid,
-                                       a.fin_tag);
-    if (tid == 0) __hip_atomic_store(a.fin_count + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    row[tid] = v;  // the fixed-order sum follows as its own launch (abd_finalize_kernel)
   }
 }

@@ -1,0 +1,518 @@
+// abd_sampler.hip -- the native compound sampler of the C ABI (abd_sampler_*; include/abd_hip.h): the step pm.sample
+// assigns to this model (abd.py:921-922) -- NUTS on the 17 continuous variables (abd_nuts.hpp), the device Gibbs sweep on
+// [i_raw, ab_s_waner], recording of the Deterministics -- run against the evaluation path without leaving the library.
+#include "abd_host.hpp"
+#include "abd_nuts.hpp"
+
+struct abd_sampler {
+  abd_ctx* c = nullptr;
+  int n = 0;
+  abd_sampler_opts o{};
+  std::vector<int32_t> chains;
+  std::vector<abdnuts::AdaptiveNuts> ch;
+  int64_t it = 0;
+  double* d_sums = nullptr;  // [n][3][G*N]
+  int64_t n_accumulated = 0;
+  // recording: device staging of up to rec_chunk draws per chain, [n][rec_chunk][...] per variable
+  int64_t rec_chunk = 0;
+  double* d_rec_mu = nullptr;   // [2][n][rec_chunk][G*N]  (ab_n_mu, ab_s_mu)
+  int8_t* d_rec_i8 = nullptr;   // [2][n][rec_chunk][G*N]  (i_raw, i) then [n][rec_chunk][N] (waner)
+  std::vector<double> lp, gr;  // starting points' logp / gradient
+  int unit = 1;                // chains per independent unit (sampler_run_units)
+  int threads = 1;  // host threads that drive the units (sampler_run_units)
+};
+
+namespace {
+
+// add chain k's Deterministics at its current point to its running sums (stream st)
+int accumulate_chain(abd_sampler* s, int k, hipStream_t st) {
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N;
+  return launch_deterministics(c, s->chains[(size_t)k], s->ch[(size_t)k].nuts.q, st, nullptr, nullptr, nullptr,
+                               s->d_sums + (size_t)k * 3 * cells);
+}
+
+}  // namespace
+
+extern "C" {
+
+int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta0, const abd_sampler_opts* opts,
+                       abd_sampler** out) {
+  if (!c || !chains || !theta0 || !opts || !out) return fail(ABD_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  int rc = check_chains(c, n, chains);
+  if (rc) return rc;
+  for (int a = 0; a < n; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (chains[a] == chains[b]) return fail(ABD_ERR_ARG, "chain %d listed twice", chains[a]);
+  if (opts->tune < 0) return fail(ABD_ERR_ARG, "tune=%lld is negative", (long long)opts->tune);
+  if (opts->chain_offset < 0) return fail(ABD_ERR_ARG, "chain_offset=%d is negative", opts->chain_offset);
+  if (opts->max_treedepth < 1 || opts->max_treedepth > abdnuts::MAX_DEPTH)
+    return fail(ABD_ERR_ARG, "max_treedepth=%d outside [1, %d]", opts->max_treedepth, abdnuts::MAX_DEPTH);
+  if (!(opts->target_accept > 0.0 && opts->target_accept < 1.0))
+    return fail(ABD_ERR_ARG, "target_accept=%g outside (0, 1)", opts->target_accept);
+  abd_sampler* s = new (std::nothrow) abd_sampler();
+  if (!s) return fail(ABD_ERR_NOMEM, "out of host memory");
+  s->c = c;
+  s->n = n;
+  s->o = *opts;
+  s->chains.assign(chains, chains + n);
+  s->ch.resize((size_t)n);
+  s->lp.resize((size_t)n);
+  s->gr.resize((size_t)n * ABD_N_THETA);
+  // chains per unit: a large dense cohort keeps the chip busy with one chain per launch and gains most from chains
+  // that never wait for each other; a small cohort is bound by the host's ~6 us per launch, which a unit's chains share
+  // (measured, tools/probe_nuts_rate.py: config 3 -- 8 chains 88 k evals/s with units of 1, 82 k with 4; 16 chains 92 k / 112 k;
+  // default cohort, 16 chains -- 152 k with units of 1, 334 k with 4, 359 k with 8)
+  // host threads that drive the units: one for dense cohorts (bound by the device), up to four for observation lists
+  // (bound by the host's two launches per evaluation)
+  s->threads = c->dense ? 1 : 4;
+  s->threads = std::max(1, std::min(16, env_int("ABD_SAMPLER_THREADS", s->threads)));
+  // With four host threads (observation lists) the best split is four units -- one per thread and per
+  // hardware queue: default cohort, evaluations/s seen by NUTS with 4 / 8 / 16 chains 217 k / 339 k / 491 k against
+  // 166 k / 253 k / 300-370 k for the best split on one thread.
+  // Large dense cohorts (one host thread): at most about four units -- the hardware queues -- of 1, 2, 4 or 8 chains, the
+  // sizes the dense kernel has a shape for (config 3, evaluations/s seen by NUTS over 150-300 iterations: 8 chains 79 k
+  // with units of 1, 112 k with 2; 12 chains 97 k / 88 k / 83 k with 2 / 3 / 4; 16 chains 91 k / 100 k with 2 / 4;
+  // 32 chains 100 k / 134 k with 4 / 8)
+  int dense_unit = 1;
+  while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
+  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
+  s->unit = env_int("ABD_SAMPLER_UNIT", s->unit);
+  s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
+
+  // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers
+  // must not depend on it
+  c->group_blocks = std::min(c->dense_blocks, c->n_cu);
+  if (const int gb = tune_int("ABD_GROUP_BLOCKS_PER_CU", 0)) c->group_blocks = std::max(1, std::min(c->n_cu * gb, c->blocks_max));
+  // the starting points through the launch shape the units will use
+  rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
+  if (!rc && (n + s->unit - 1) / s->unit > 1 && tune_int("ABD_PROBE_QUEUES", 1) != 0) rc = probe_stream_queues(c);
+  for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
+    const int m = std::min(s->unit, n - lo);
+    rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, unit_pipe(c, u));
+    if (!rc) rc = wait_rows(c, kSyncSlot + u, m, c->seq, c->pipe[unit_pipe(c, u)].st);
+    if (!rc) rc = fetch_slot(c, kSyncSlot + u, s->lp.data() + lo, s->gr.data() + (size_t)lo * ABD_N_THETA);
+  }
+  if (rc) {
+    delete s;
+    return rc;
+  }
+  for (int k = 0; k < n; ++k) {
+    if (!std::isfinite(s->lp[(size_t)k])) {
+      delete s;
+      return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
+    }
+    s->ch[(size_t)k].init(theta0 + (size_t)k * ABD_N_THETA, s->lp[(size_t)k], s->gr.data() + (size_t)k * ABD_N_THETA,
+                          opts->seed, (uint64_t)((int64_t)chains[k] + opts->chain_offset), opts->tune, opts->max_treedepth, opts->target_accept,
+                          opts->dense_metric != 0);
+  }
+  if (opts->accumulate) {
+    const size_t bytes = (size_t)n * 3 * c->G * c->N * sizeof(double);
+    hipError_t e = hipMalloc(&s->d_sums, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_sums, 0, bytes, c->stream);
+    if (e != hipSuccess) {
+      if (s->d_sums) (void)hipFree(s->d_sums);
+      delete s;
+      return fail(ABD_ERR_HIP, "sampler sums: %s", hipGetErrorString(e));
+    }
+  }
+  *out = s;
+  return ABD_OK;
+}
+
+void abd_sampler_destroy(abd_sampler* s) {
+  if (!s) return;
+  if (s->d_sums || s->d_rec_mu || s->d_rec_i8) {
+    (void)hipSetDevice(s->c->device);
+    (void)hipStreamSynchronize(s->c->stream);
+    if (s->d_sums) (void)hipFree(s->d_sums);
+    if (s->d_rec_mu) (void)hipFree(s->d_rec_mu);
+    if (s->d_rec_i8) (void)hipFree(s->d_rec_i8);
+  }
+  delete s;
+}
+
+int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats) {
+  return abd_sampler_run_record(s, n_iter, theta, stats, nullptr);
+}
+
+namespace {
+
+// copy staged draws [0, filled) of chain k to the caller's arrays, starting at draw `first` (stream st, waited for)
+int record_flush_chain(abd_sampler* s, const abd_record* rec, int k, int64_t first, int64_t filled, hipStream_t st) {
+  if (filled == 0) return ABD_OK;
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
+  const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
+  const size_t dev = (size_t)k * s->rec_chunk, host = (size_t)k * rec->capacity + first;
+  if (rec->ab_n_mu) HIP_TRY(hipMemcpyAsync(rec->ab_n_mu + host * cells, s->d_rec_mu + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (rec->ab_s_mu) HIP_TRY(hipMemcpyAsync(rec->ab_s_mu + host * cells, s->d_rec_mu + per_var + dev * cells, filled * cells * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (rec->i_raw) HIP_TRY(hipMemcpyAsync(rec->i_raw + host * cells, s->d_rec_i8 + dev * cells, filled * cells, hipMemcpyDeviceToHost, st));
+  if (rec->i) HIP_TRY(hipMemcpyAsync(rec->i + host * cells, s->d_rec_i8 + per_var + dev * cells, filled * cells, hipMemcpyDeviceToHost, st));
+  if (rec->ab_s_waner) HIP_TRY(hipMemcpyAsync(rec->ab_s_waner + host * N, s->d_rec_i8 + 2 * per_var + dev * N, filled * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ABD_OK;
+}
+
+// stage the current draw of chain k at position `pos` of its chunk (all asynchronous on stream st)
+int record_stage_chain(abd_sampler* s, const abd_record* rec, int k, int64_t pos, hipStream_t st) {
+  abd_ctx* c = s->c;
+  const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
+  const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
+  const size_t at = ((size_t)k * s->rec_chunk + pos);
+  const int chain = s->chains[(size_t)k];
+  const ChainSlot& slot = c->slots[(size_t)chain];
+  if (rec->i || rec->ab_n_mu || rec->ab_s_mu)
+    if (int rc = launch_deterministics(c, chain, s->ch[(size_t)k].nuts.q, st, rec->i ? s->d_rec_i8 + per_var + at * cells : (int8_t*)nullptr,
+                                       rec->ab_n_mu ? s->d_rec_mu + at * cells : (double*)nullptr,
+                                       rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, nullptr))
+      return rc;
+  if (rec->i_raw)
+    if (int rc = launch_unpack(c, chain, s->d_rec_i8 + at * cells, st)) return rc;
+  if (rec->ab_s_waner)
+    HIP_TRY(hipMemcpyAsync(s->d_rec_i8 + 2 * per_var + at * N, slot.waner, N, hipMemcpyDeviceToDevice, st));
+  return ABD_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// The sampler's chains run as independent UNITS of `unit` consecutive chains (1 for large dense cohorts, 4 otherwise;
+// abd_sampler_create), unit u on HIP stream u mod 8 with its own private result rows (slot kSyncSlot + u):
+//   tree:      one evaluation launch per leapfrog for the unit's chains whose tree is still growing
+//   sweep:     when all its trees have stopped, the unit's Gibbs sweep and the evaluation at the new state are queued
+//              back to back on its stream (stream order: no host wait in between), counts copied to pinned memory
+//   recording: queued on the same stream behind them
+// The host polls the completion tags of whatever is in flight and moves each unit's state machine on.  No unit waits
+// for another one's trees -- in lock step an iteration lasts as long as the LONGEST tree of all chains -- and the
+// units' launches overlap on the device.  Within a unit the chains share launches (small cohorts are launch-bound:
+// ~6 us of host time per evaluation launch).  Same compound step per chain, same random streams, and the numbers a
+// unit's launch produces depend only on the unit (fixed grid), never on the other units or on timing.
+int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec, bool recording) {
+  abd_ctx* c = s->c;
+  const int n = s->n, B = s->unit;
+  const int n_units = (n + B - 1) / B;
+  enum { EVAL, POST, DONE };
+  struct Unit {
+    int lo = 0, hi = 0, m = 0, state = EVAL;
+    int64_t k = 0;       // iterations completed in this call
+    int64_t staged = 0;  // draws staged on the device, not yet copied out
+    int64_t flushed_to = 0;
+    double tag = 0.0;
+    std::chrono::steady_clock::time_point t_queued;  // profile: when its last evaluation had been queued
+    std::vector<int32_t> ids, who;
+    std::vector<double> th, lp, gr;
+  };
+  std::vector<Unit> units((size_t)n_units);
+  // host threads (see below): a power of two <= 8, so that units that share a HIP stream (u and u + 8) share their thread
+  // (one thread while abd_kernel_timing is on: the event bookkeeping of enqueue_group belongs to the context, not to a unit)
+  int T_all = 1;
+  while (c->timing == 0 && 2 * T_all <= std::min({s->threads, n_units, (int)kMaxPipes})) T_all *= 2;
+  // one completion-tag sequence per unit, disjoint from the context's and from each other's (unit u: (u + 1) 2^40 + k).  It
+  // belongs to the CONTEXT, like the result rows kSyncSlot + u the tags are compared against: monotone for the life of
+  // those rows, whichever sampler drives them
+  while (c->unit_seq.size() < (size_t)n_units) c->unit_seq.push_back((double)(c->unit_seq.size() + 1) * 1099511627776.0);
+  HIP_TRY(hipSetDevice(c->device));
+  if (int frc = flush_ring(c)) return frc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first
+  auto stream_of = [&](int u) { return c->pipe[unit_pipe(c, u)].st; };
+  // evaluate the points th[0 .. m) of the unit's chains who[0 .. m)
+  auto launch_eval = [&](int u) -> int {
+    Unit& un = units[(size_t)u];
+    double* seqp = T_all > 1 ? &c->unit_seq[(size_t)u] : nullptr;
+    int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u), seqp);
+    if (rc) return rc;
+    un.tag = seqp ? *seqp : c->seq;
+    un.t_queued = std::chrono::steady_clock::now();
+    return ABD_OK;
+  };
+  auto launch_tree = [&](int u) -> int {  // the next leapfrog of every tree of the unit that is still growing
+    Unit& un = units[(size_t)u];
+    un.m = 0;
+    for (int j = un.lo; j < un.hi; ++j) {
+      abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+      if (!nu.active) continue;
+      un.ids[(size_t)un.m] = s->chains[(size_t)j];
+      un.who[(size_t)un.m] = j;
+      std::memcpy(un.th.data() + (size_t)un.m * ABD_N_THETA, nu.request(), sizeof(double) * ABD_N_THETA);
+      ++un.m;
+    }
+    if (!un.m) return ABD_OK;
+    return launch_eval(u);
+  };
+  auto ready = [&](int u) -> bool {  // have all result rows of the unit's launch landed? (never blocks)
+    const Unit& un = units[(size_t)u];
+    volatile const double* rows = c->h_out + (size_t)(kSyncSlot + u) * c->n_slots * ABD_NOUT;
+    for (int k = un.m - 1; k >= 0; --k)
+      if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] != un.tag) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
+  };
+  // end of iteration un.k of the unit's chains (points and discrete states are final): outputs, running sums, recording;
+  // then the next iteration's first leapfrogs, or DONE
+  auto finish_iteration = [&](int u, bool with_counts) -> int {
+    Unit& un = units[(size_t)u];
+    hipStream_t st = stream_of(u);
+    const bool draw = s->it + un.k >= s->o.tune;
+    for (int j = un.lo; j < un.hi; ++j) {
+      const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+      if (theta) std::memcpy(theta + ((size_t)j * n_iter + un.k) * ABD_N_THETA, nu.q, sizeof(double) * ABD_N_THETA);
+      if (stats) {
+        double* o = stats + ((size_t)j * n_iter + un.k) * ABD_N_STATS;
+        o[ABD_STAT_LP] = nu.lp;
+        o[ABD_STAT_TREE_DEPTH] = nu.stats.tree_depth;
+        o[ABD_STAT_N_STEPS] = nu.stats.n_steps;
+        o[ABD_STAT_MEAN_TREE_ACCEPT] = nu.stats.mean_tree_accept;
+        o[ABD_STAT_STEP_SIZE] = nu.stats.step_size;
+        o[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
+        o[ABD_STAT_ENERGY] = nu.stats.energy;
+        o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
+        o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
+        o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+      }
+      if (draw && s->d_sums)
+        if (int rc = accumulate_chain(s, j, st)) return rc;
+      if (recording)
+        if (int rc = record_stage_chain(s, rec, j, un.staged, st)) return rc;
+    }
+    if (recording && ++un.staged == s->rec_chunk) {
+      for (int j = un.lo; j < un.hi; ++j)
+        if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
+      un.flushed_to += un.staged;
+      un.staged = 0;
+    }
+    un.k += 1;
+    if (un.k == n_iter) {
+      un.state = DONE;
+      if (recording)
+        for (int j = un.lo; j < un.hi; ++j)
+          if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
+      return ABD_OK;
+    }
+    for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
+    un.state = EVAL;
+    return launch_tree(u);
+  };
+  for (int u = 0; u < n_units; ++u) {
+    Unit& un = units[(size_t)u];
+    un.lo = u * B;
+    un.hi = std::min(n, un.lo + B);
+    const size_t cap = (size_t)(un.hi - un.lo);
+    un.ids.resize(cap);
+    un.who.resize(cap);
+    un.th.resize(cap * ABD_N_THETA);
+    un.lp.resize(cap);
+    un.gr.resize(cap * ABD_N_THETA);
+    un.flushed_to = recording ? rec->first : 0;
+    if (n_iter == 0) {
+      un.state = DONE;
+      continue;
+    }
+    for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
+    if (int rc = launch_tree(u)) return rc;
+  }
+  // The units are driven by T host threads, thread t the units u = t (mod T): what a thread touches is private to its
+  // units (stream, result rows, tag sequence, chains, the caller's arrays per chain) or read-only, so the threads
+  // share nothing but the HIP runtime.  T = 1 for dense cohorts (the device bounds them), up to 4 for observation lists,
+  // where the host's two launches per evaluation (~7 us) are what bounds a single thread.
+  // ABD_SAMPLER_PROFILE=1: how much of the wall time a host thread spends handling results and queueing launches.
+  static const bool profile = env_int("ABD_SAMPLER_PROFILE", 0) != 0;
+  const int T = T_all;
+  g_launch_profile = LaunchProfile();
+  g_launch_profile.on = profile && T == 1;
+  using clk = std::chrono::steady_clock;
+  std::atomic<int> first_error{ABD_OK};
+  std::vector<std::string> errors((size_t)T);
+  auto worker = [&](int tid) -> int {
+    if (hipSetDevice(c->device) != hipSuccess) return fail(ABD_ERR_HIP, "hipSetDevice failed");
+    const clk::time_point t_begin = clk::now();
+    clk::time_point t_handle;
+    double busy_s = 0.0, prof_fetch = 0.0, prof_feed = 0.0, prof_launch = 0.0, prof_wait = 0.0;
+    long handled = 0;
+    for (long spins = 0;;) {
+      bool any = false, progressed = false;
+      if (first_error.load(std::memory_order_relaxed) != ABD_OK) return ABD_OK;  // another thread failed: stop queueing
+      for (int u = tid; u < n_units; u += T) {
+        Unit& un = units[(size_t)u];
+        if (un.state == DONE) continue;
+        any = true;
+        if (progressed && profile) {  // close the previous unit's handling interval
+          busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
+          t_handle = clk::now();
+        }
+        if (!ready(u)) continue;
+        if (profile && !progressed) t_handle = clk::now();
+        if (profile) prof_wait += std::chrono::duration<double>(clk::now() - un.t_queued).count();
+        progressed = true;
+        ++handled;
+        clk::time_point tp0;
+        if (profile) tp0 = clk::now();
+        if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
+        if (profile) {
+          const clk::time_point t1 = clk::now();
+          prof_fetch += std::chrono::duration<double>(t1 - tp0).count();
+          tp0 = t1;
+        }
+        if (un.state == EVAL) {
+          for (int q = 0; q < un.m; ++q)
+            s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+          if (profile) {
+            const clk::time_point t1 = clk::now();
+            prof_feed += std::chrono::duration<double>(t1 - tp0).count();
+            tp0 = t1;
+          }
+          const int lrc = launch_tree(u);
+          if (profile) prof_launch += std::chrono::duration<double>(clk::now() - tp0).count();
+          if (lrc) return lrc;
+          if (un.m) continue;  // some tree of the unit is still growing
+          for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].end_transition();
+          if (!s->o.gibbs) {
+            if (int rc = finish_iteration(u, false)) return rc;
+            continue;
+          }
+          // binary Gibbs-Metropolis on [i_raw, ab_s_waner] of the unit's chains, then logp and gradient at the new
+          // states: queued back to back on the unit's stream
+          hipStream_t st = stream_of(u);
+          un.m = un.hi - un.lo;
+          for (int j = un.lo; j < un.hi; ++j) {
+            un.ids[(size_t)(j - un.lo)] = s->chains[(size_t)j];
+            un.who[(size_t)(j - un.lo)] = j;
+            std::memcpy(un.th.data() + (size_t)(j - un.lo) * ABD_N_THETA, s->ch[(size_t)j].nuts.q, sizeof(double) * ABD_N_THETA);
+          }
+          if (int rc = enqueue_gibbs(c, un.m, un.ids.data(), un.th.data(), (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + un.k),
+                                     (uint32_t)s->o.chain_offset, st, c->d_counts_chain + 2 * (size_t)un.lo,
+                                     c->d_work + c->n_slots + un.lo, nullptr))
+            return rc;
+          HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)un.lo, c->d_counts_chain + 2 * (size_t)un.lo,
+                                 (size_t)un.m * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+          un.state = POST;
+          if (int rc = launch_eval(u)) return rc;
+        } else {  // POST: the sweep and the evaluation behind it are done (the counts landed before: same stream)
+          for (int q = 0; q < un.m; ++q)
+            s->ch[(size_t)un.who[(size_t)q]].nuts.set_point(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+          if (int rc = finish_iteration(u, true)) return rc;
+        }
+      }
+      if (progressed && profile) busy_s += std::chrono::duration<double>(clk::now() - t_handle).count();
+      if (!any) break;
+      if (progressed) {
+        spins = 0;
+      } else if (++spins > 4000000) {
+        __atomic_fetch_add(&c->wait_fallbacks, (int64_t)1, __ATOMIC_RELAXED);  // no tag for tens of ms: synchronise the streams in flight (see abd_wait_fallbacks)
+        for (int u = tid; u < n_units; u += T)
+          if (units[(size_t)u].state != DONE) HIP_TRY(hipStreamSynchronize(stream_of(u)));
+        spins = 0;
+      } else {
+        __builtin_ia32_pause();
+      }
+    }
+    if (profile) {
+      const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
+      std::fprintf(stderr, "abd sampler: thread %d of %d, %d units of %d chains in all, %ld results handled in %.3f s: host busy %.0f %% "
+                   "(%.2f us per result: %.2f assemble, %.2f NUTS, %.2f queueing the next evaluation); evaluation queued -> result seen %.2f us\n",
+                   tid, T, n_units, B, handled, wall, 100.0 * busy_s / wall, handled ? 1e6 * busy_s / handled : 0.0,
+                   handled ? 1e6 * prof_fetch / handled : 0.0, handled ? 1e6 * prof_feed / handled : 0.0,
+                   handled ? 1e6 * prof_launch / handled : 0.0, handled ? 1e6 * prof_wait / handled : 0.0);
+      if (g_launch_profile.on)
+        std::fprintf(stderr, "abd sampler: inside hipLaunchKernelGGL: %.2f us per evaluation launch (%ld), %.2f us per sum launch (%ld)\n",
+                     g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0, g_launch_profile.evals,
+                     g_launch_profile.sums ? 1e6 * g_launch_profile.sum_s / g_launch_profile.sums : 0.0, g_launch_profile.sums);
+    }
+    return ABD_OK;
+  };
+  auto run_worker = [&](int tid) {
+    const int rc = worker(tid);
+    if (rc != ABD_OK) {
+      errors[(size_t)tid] = last_error();  // the message is thread-local: hand it to the calling thread
+      int expected = ABD_OK;
+      first_error.compare_exchange_strong(expected, rc);
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(run_worker, t);
+    run_worker(0);
+    for (auto& th : pool) th.join();
+  }
+  g_launch_profile.on = false;
+  if (first_error.load() != ABD_OK) {
+    for (int t = 0; t < T; ++t)
+      if (!errors[(size_t)t].empty()) return fail(first_error.load(), "%s", errors[(size_t)t].c_str());
+    return fail(first_error.load(), "sampler thread failed");
+  }
+  // the context's stream continues behind everything the units queued
+  for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;
+  if (int jrc = join_pipes(c)) return jrc;
+  const int64_t first_draw = std::max<int64_t>(s->it, s->o.tune);
+  if (s->d_sums && s->it + n_iter > first_draw) s->n_accumulated += s->it + n_iter - first_draw;
+  s->it += n_iter;
+  return ABD_OK;
+}
+
+}  // namespace
+
+int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (n_iter < 0) return fail(ABD_ERR_ARG, "n_iter=%lld is negative", (long long)n_iter);
+  abd_ctx* c = s->c;
+  const int n = s->n;
+  const bool recording = rec && (rec->i_raw || rec->ab_s_waner || rec->i || rec->ab_n_mu || rec->ab_s_mu);
+  if (recording) {
+    if (rec->first < 0 || rec->first + n_iter > rec->capacity)
+      return fail(ABD_ERR_ARG, "record: draws [%lld, %lld) do not fit capacity %lld", (long long)rec->first,
+                  (long long)(rec->first + n_iter), (long long)rec->capacity);
+    if (!s->d_rec_mu) {
+      HIP_TRY(hipSetDevice(c->device));
+      const size_t cells = (size_t)c->G * c->N;
+      const size_t per_draw = (size_t)n * (cells * 18 + c->N);  // bytes staged per draw, all chains
+      s->rec_chunk = std::max<int64_t>(1, std::min<int64_t>(256, (int64_t)(((size_t)256 << 20) / per_draw)));
+      double* mu = nullptr;
+      int8_t* i8 = nullptr;
+      hipError_t e = hipMalloc(&mu, (size_t)2 * n * s->rec_chunk * cells * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&i8, (size_t)2 * n * s->rec_chunk * cells + (size_t)n * s->rec_chunk * c->N);
+      if (e != hipSuccess) {
+        if (mu) (void)hipFree(mu);
+        return fail(ABD_ERR_HIP, "record staging: %s", hipGetErrorString(e));
+      }
+      s->d_rec_mu = mu;
+      s->d_rec_i8 = i8;
+    }
+  }
+  return sampler_run_units(s, n_iter, theta, stats, rec, recording);
+}
+
+int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* mu_n_mean, double* mu_s_mean, int64_t* n_draws) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
+  if (!s->d_sums) return fail(ABD_ERR_STATE, "the sampler was created without accumulate");
+  abd_ctx* c = s->c;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t cells = (size_t)c->G * c->N;
+  double* outs[3] = {i_mean, mu_n_mean, mu_s_mean};
+  const double inv = s->n_accumulated ? 1.0 / (double)s->n_accumulated : 0.0;
+  for (int v = 0; v < 3; ++v) {
+    if (!outs[v]) continue;
+    HIP_TRY(hipMemcpy(outs[v], s->d_sums + ((size_t)k * 3 + v) * cells, cells * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < cells; ++e) outs[v][e] *= inv;
+  }
+  if (n_draws) *n_draws = s->n_accumulated;
+  return ABD_OK;
+}
+
+int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
+  const abdnuts::Nuts& nu = s->ch[(size_t)k].nuts;
+  if (inv_mass) std::memcpy(inv_mass, nu.inv_mass, sizeof(double) * ABD_N_THETA);
+  if (step_size) *step_size = nu.eps;
+  if (metric)
+    for (int r = 0; r < ABD_N_THETA; ++r)
+      for (int c = 0; c < ABD_N_THETA; ++c)
+        metric[r * ABD_N_THETA + c] = nu.dense ? nu.cov[r][c] : (r == c ? nu.inv_mass[r] : 0.0);
+  return ABD_OK;
+}
+
+}  // extern "C"

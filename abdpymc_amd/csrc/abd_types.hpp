@@ -1,0 +1,152 @@
+// abd_types.hpp -- constants and plain structs shared by the device code and its host launchers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ABD_MAXT 4          // 64-gap words per individual (G <= 256)
+#define ABD_NACC 13         // floating sums per chain (see enum below)
+#define ABD_NOUT 16         // ABD_NACC + n1 + m1, padded
+#define ABD_MAX_BATCH_K 16  // chains per launch
+#define ABD_WAVES_PER_BLOCK 4
+#define ABD_BLOCK (64 * ABD_WAVES_PER_BLOCK)
+
+// raw sums accumulated on the device; per-chain constants are applied on the host (abd_capi.hip: assemble)
+//   q = od - d s,  s = 1 / (1 + exp(b (a - x))),  h' = q s (1 - s)
+//   d ll / d a = -b (d / sigma^2) h'
+enum {
+  A_N_Q2 = 0,   // sum q^2                        -> ll, d/d log sigma
+  A_N_H,        // sum h'            -> init_n
+  A_N_HC,       // sum h' [cumI>0]   -> perm_n
+  A_N_HU,       // sum h' U_n        -> temp_n    U_n = sum_r rho_n^(g-r)
+  A_N_HD,       // sum h' dU_n/drho  -> rho_n
+  A_N_HX,       // sum h' (a - x)    -> b_n
+  A_N_QS,       // sum q s           -> d_n
+  A_S_Q2,
+  A_S_H,
+  A_S_HC,
+  A_S_HD,
+  A_S_HX,
+  A_S_QS,
+};
+
+struct ChainPar {
+  double perm_n, temp_n, rho_n, init_n;
+  double perm_s, rho_s, init_s;
+  double b_n, d_n;
+  double b_s, d_s;
+  const uint64_t* rw;   // [nt][N] packed i_raw of the chain
+  const int8_t* waner;  // [N]
+};
+
+struct EvalArgs {
+  // sparse observation lists (CSR by individual)
+  const void* y_n;
+  const void* x_n;
+  const void* y_s;
+  const void* x_s;
+  const uint8_t* g_n;
+  const uint8_t* g_s;
+  const int32_t* ptr_n;
+  const int32_t* ptr_s;
+  const int32_t* j_n;  // individual of each observation (observation-lane kernel)
+  const int32_t* j_s;
+  int32_t K_n, K_s;          // list lengths
+  int32_t ob_n, ob_s, ob_c;  // observation-lane kernel: workgroups over the N list, the S list, the individuals
+  int32_t pad3_;
+  // dense panels, gap-major [G][N] of {od, log_dilution}
+  const void* yx_n;
+  const void* yx_s;
+  // packed indicator panels [nt][N]
+  const uint64_t* vw;
+  const uint64_t* pw;  // nullptr = ignore_pcrpos
+#ifdef ABD_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [grid.x][16] s_memrealtime at phase boundaries
+#endif
+  const int32_t* range_tab;  // dense kernel: {first lane group, first gap, rows, 0} of every range of this launch shape
+  const double* exp2_tab;  // dense kernel: 2^(j/1024), j = 0..1023, correctly rounded (copied to LDS per workgroup)
+  double* partials;    // [n_chains][grid.x][ABD_NOUT]
+  // dense kernel only: the fixed-order sum of the PREVIOUS launch's partials, done by the first
+  // prev_n_chains workgroups of this launch (saves a kernel and a boundary per step when launches are
+  // stream-ordered); prev_n_chains = 0 -> nothing to do
+  const double* prev_partials;
+  double* prev_out;
+  int32_t prev_n_chains, prev_blocks;
+  int32_t fin_rows;    // gap rows the finalizing workgroups are excused from
+  int32_t xcd_remap;   // dense kernel: workgroup -> range mapping that keeps neighbouring ranges on one XCD
+  double prev_tag;          // completion tag of the previous launch (see finalize_chain)
+  // observation-lane kernel: the workgroup of a chain that finishes last sums that chain's partial rows itself
+  // (abd_obs.hpp) -- one launch per evaluation instead of two.  fin_count: one zeroed counter per grid row.
+  unsigned int* fin_count;
+  double* fin_out;
+  double fin_tag;
+  int32_t G, N, nt, n_chunks;
+  int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
+  uint64_t chunk_mask[3][ABD_MAXT];
+  ChainPar ch[ABD_MAX_BATCH_K];
+};
+
+struct double2_t {
+  double x, y;
+};
+
+template <typename R>
+struct YX {
+  R y, x;
+};
+
+
+#define ABD_EXP2_TAB 1024  // entries of the 2^(j/1024) table (8 KB of LDS per workgroup)
+
+struct Philox4 {
+  uint32_t w[4];
+};
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                          uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.w[0] = c0;
+  o.w[1] = c1;
+  o.w[2] = c2;
+  o.w[3] = c3;
+  return o;
+}
+
+#define ABD_TRANSIT_P_U32 3435973836u  // floor(0.8 * 2^32): propose iff word 1 < this   (transit_p = 0.8)
+#define ABD_GIBBS_WAVE_LDS 3904        // per wave: keys u32[260] + order u16[260] + transit u8[260] (padded to 264) + log u f64[260]
+
+struct GibbsArgs {
+  EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)
+  uint32_t seed_lo, seed_hi, sweep;
+  uint32_t ind_offset;  // added to the individual's index in the Philox counter (cohort sharded by individual)
+  uint32_t stream[ABD_MAX_BATCH_K];  // third counter word of each chain: its slot id (+ the caller's offset)
+  double theta0[ABD_MAX_BATCH_K];  // log p - log(1 - p)             = p_logodds__
+  double theta7[ABD_MAX_BATCH_K];  // log p_waner - log(1 - p_waner) = ab_s_p_waner_logodds__
+  double is2_n[ABD_MAX_BATCH_K];   // 1 / sigma_n^2
+  double is2_s[ABD_MAX_BATCH_K];
+  unsigned long long* counts;      // [n_chains][2]: accepted, proposed (integer atomics: order-free)
+  unsigned int* work;              // [n_chains]: next individual of each chain (abd_gibbs_dense_kernel's work queue), zeroed per launch
+  unsigned long long* stats;       // nullptr, or 8 development counters of abd_gibbs_dense_kernel (ABD_GIBBS_STATS=1)
+  int32_t refill_min, tail_lanes, tail_age;  // scheduler knobs of abd_gibbs_dense_kernel (abd_gibbs2.hpp)
+};
+
+
+// scheduler constants of abd_gibbs_dense_kernel (abd_gibbs2.hpp)
+#define ABD_G2_REFILL_MIN 16         // idle lanes that trigger a refill (a refill costs ~2-3 walk steps)
+#define ABD_G2_TAIL_LANES 8          // walkers left when the whole wave starts finishing them one at a time ...
+#define ABD_G2_TAIL_AGE 6            // ... those that have survived this many gaps

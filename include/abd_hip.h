@@ -164,8 +164,10 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
  * for another one's trees (as PyMC's one process per chain does not), and their launches overlap on the device.
  * What a unit computes depends only on the unit (fixed launch shape), never on the other units or on timing.
  * Cohorts kept as observation lists are bound by the host's two kernel launches per evaluation, so their units are
- * driven by up to four host threads inside abd_sampler_run (thread t the units t, t + 4, ...: what a thread touches is
- * private to its units); dense cohorts are bound by the device and use the calling thread only.
+ * driven by T host threads inside abd_sampler_run (T a power of two <= 8, 4 by default; thread t the units u with
+ * u mod T == t: what a thread touches is private to its units); dense cohorts are bound by the device and use the calling
+ * thread only.  abd_kernel_timing and the threaded sampler are mutually exclusive: while a timing mode is on, the units
+ * are driven by the calling thread alone.
  * Step size: dual averaging to `target_accept`; metric: diagonal, windowed running variance of the tuning draws
  * (abdpymc_amd/csrc/abd_nuts.hpp).
  * Iterations [0, tune) adapt; later ones are draws.  Randomness: one xoshiro256++ stream per chain keyed by
@@ -252,15 +254,11 @@ int abd_set_individual_offset(abd_ctx* ctx, int64_t first_individual);
  * mode 0: off.  abd_kernel_time returns the accumulated device time and launch count since the last reset
  * (synchronises). */
 int abd_kernel_timing(abd_ctx* ctx, int32_t mode);
-/* Synchronous calls wait for their result rows by polling a completion tag in mapped host memory; if a tag does not
- * show within ~2 M polls the call falls back to a stream synchronise (still correct).  Number of such fall-backs
- * since abd_create: anything but 0 means the tag path has regressed. */
+/* Every waiting call (synchronous evaluations, abd_wait, abd_logp_dlogp_many, the native sampler) waits for its result
+ * rows by polling a completion tag in mapped host memory; if a tag does not show in time (~2 M polls / 1 s) the call
+ * falls back to a stream synchronise, checks the tags again and fails with ABD_ERR_STATE if a row still lacks its tag.
+ * Number of such fall-backs since abd_create: anything but 0 means the tag path has regressed. */
 int64_t abd_wait_fallbacks(abd_ctx* ctx);
-/* The native sampler keeps the evaluation kernel of a dense cohort's chain resident on the device for a whole NUTS
- * trajectory and feeds it commands through mapped host memory (see abd_sampler_create).  Since abd_create: kernels
- * launched, evaluations they served, and relaunches after a kernel left on its own because the host did not send a
- * command within its time-out (harmless, but expected to stay 0 on an idle machine).  Any pointer may be NULL. */
-int abd_resident_stats(abd_ctx* ctx, int64_t* launches, int64_t* commands, int64_t* restarts);
 /* HIP multiplexes its streams over a few hardware queues, and kernels of streams that share a queue run one after the
  * other.  Measures (once per context, ~0.5 ms) which of the context's n <= 8 streams share one: streams with the same
  * number in queue_of_stream[] do.  The native sampler gives its units streams of different queues first. */
@@ -282,6 +280,24 @@ int64_t abd_algorithmic_bytes(abd_ctx* ctx, int32_t n_chains);
 int abd_is_dense(abd_ctx* ctx);
 /* HIP streams that stream-ordered dense launches rotate over (1 for cohorts kept as observation lists). */
 int abd_n_pipes(abd_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Environment variables the library reads (all optional; read at abd_create / abd_sampler_create / first use).
+ * This table is complete: the product library calls getenv for nothing else (development knobs of launch shapes
+ * exist only in a tuning build compiled with -DABD_TUNING, tools/README.md).
+ *
+ *   variable             default             meaning
+ *   ABD_PIPES            4                   HIP streams (one per hardware queue) that stream-ordered dense launches
+ *                                            rotate over; 1 = every launch alone on the context's stream (profiling)
+ *   ABD_OBS_LANES        by list density     observation lists: 1 = lane-per-observation kernel, 0 = wave-per-individual
+ *   ABD_FORCE_SPARSE     0                   1 = keep a dense panel as observation lists (exercises the list kernels)
+ *   ABD_GIBBS_V1         0                   1 = dense cohorts sweep with the wave-per-proposal kernel (cross-check)
+ *   ABD_DENSE_OWN_SUM    1                   0 = a sampler unit's dense launch is summed by a second launch (same bits)
+ *   ABD_SAMPLER_THREADS  1 dense / 4 lists   host threads that drive the native sampler's units (<= 8 are used)
+ *   ABD_SAMPLER_UNIT     by cohort           chains per independent unit of the native sampler
+ *   ABD_SAMPLER_PROFILE  0                   1 = abd_sampler_run reports on stderr where the host thread's time went
+ *   ABD_GIBBS_STATS      0                   1 = abd_gibbs_sweep reports the dense sweep's scheduler counters on stderr
+ * (The Python layer adds ABD_HIP_LIB, the path of this library, and bench.py ABD_DIST_BACKEND.) */
 
 #ifdef __cplusplus
 }

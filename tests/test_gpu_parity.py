@@ -112,34 +112,6 @@ def test_sparse_many_obs_per_individual(lanes, monkeypatch):
         assert_close(lp[c], g[c], *refs[c])
 
 
-def test_observation_kernel_fused_sum_gives_the_same_bits(monkeypatch):
-    """ABD_OBS_FUSED_SUM=1: the lane-per-observation kernel sums its own partial rows (last workgroup in, device-coherent
-    re-read) instead of a second launch -- same order of additions, so the same bits, call after call and for every
-    chain of a batch."""
-    coh = random_sparse_cohort(700, 60, 9000, 8000, seed=21)
-    states = [_state(coh, 30 + c) for c in range(3)]
-    out = {}
-    for fused in ("0", "1"):
-        monkeypatch.setenv("ABD_OBS_LANES", "1")
-        monkeypatch.setenv("ABD_OBS_FUSED_SUM", fused)
-        ctx = _ctx(coh, (20, 41), n_chains=3)
-        for c, (_, i_raw, w) in enumerate(states):
-            ctx.set_discrete(c, i_raw, w)
-        res = []
-        for rep in range(20):
-            th = np.array([states[c][0] + 0.01 * rep for c in range(3)])
-            res.append(ctx.logp_dlogp_batch([0, 1, 2], th))
-            res.append(ctx.logp_dlogp(rep % 3, th[rep % 3]))
-        out[fused] = res
-        assert ctx.wait_fallbacks == 0
-        ctx.close()
-    for (lp0, g0), (lp1, g1) in zip(out["0"], out["1"]):
-        np.testing.assert_array_equal(np.asarray(lp0), np.asarray(lp1))
-        np.testing.assert_array_equal(np.asarray(g0), np.asarray(g1))
-    lp_ref, g_ref = O.logp_dlogp(states[0][0], states[0][1], states[0][2], coh, (20, 41))
-    assert_close(out["1"][0][0][0], out["1"][0][1][0], lp_ref, g_ref)
-
-
 def test_sparse_lists_longer_than_the_grid(monkeypatch):
     """The lane-per-observation grid is capped (8 workgroups per CU and list): lanes stride over longer lists."""
     monkeypatch.setenv("ABD_OBS_LANES", "1")

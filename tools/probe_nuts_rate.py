@@ -46,5 +46,5 @@ dt = time.perf_counter() - t0
 evals = float(st["n_steps"].sum())
 print(f"{cfg} chains={C} unit={os.environ.get('ABD_SAMPLER_UNIT', 'auto')}: {evals / dt:,.0f} evals/s as seen by NUTS "
       f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains, "
-      f"{dt / (evals / C) * 1e6:.1f} us per leapfrog of a chain); resident kernels: {ctx.resident_stats}")
+      f"{dt / (evals / C) * 1e6:.1f} us per leapfrog of a chain); wait fall-backs {ctx.wait_fallbacks}")
 smp.close()

@@ -39,10 +39,12 @@ Transformed transform(const double* t) {
   c.tinf = std::exp(t[8]);
   c.tvac = std::exp(t[9]);
   c.init_s = t[10];
-  c.b_n = t[11];
+  // b = 0 (a flat curve) is replaced by the smallest scale that keeps c = 1024 log2(e) b a normal number: the logistic
+  // term is 1/2 to the last bit either way, and the dense kernel's sum for d/db, which it returns scaled by c, stays defined
+  c.b_n = t[11] == 0.0 ? 1e-300 : t[11];
   c.d_n = t[12];
   c.sig_n = std::exp(t[13]);
-  c.b_s = t[14];
+  c.b_s = t[14] == 0.0 ? 1e-300 : t[14];
   c.d_s = t[15];
   c.sig_s = std::exp(t[16]);
   return c;
@@ -157,13 +159,17 @@ void assemble(const abd_ctx* c, const HostTerms& h, const double* t, const doubl
     grad[2] += fn * tr.temp_n * sums[A_N_HU];
     grad[3] += fn * tr.temp_n * tr.rho_n * (1.0 - tr.rho_n) * sums[A_N_HD];
     grad[4] += fn * sums[A_N_H];
-    grad[11] += -tr.d_n * is2_n * sums[A_N_HX];
+    // sum h' (a - x): the dense kernel returns it times c = 1024 log2(e) b (abd_dense.hpp), the list kernels as it is
+    const double kC = 1.4426950408889634074 * ABD_EXP2_TAB;
+    const double hx_n = c->dense ? sums[A_N_HX] / (kC * tr.b_n) : sums[A_N_HX];
+    const double hx_s = c->dense ? sums[A_S_HX] / (kC * tr.b_s) : sums[A_S_HX];
+    grad[11] += -tr.d_n * is2_n * hx_n;
     grad[12] += is2_n * sums[A_N_QS];
     grad[13] += is2_n * sums[A_N_Q2] - Kn;
     grad[5] += fs * tr.perm_s * sums[A_S_HC];
     grad[6] += fs * tr.rho_s * (1.0 - tr.rho_s) * sums[A_S_HD];
     grad[10] += fs * sums[A_S_H];
-    grad[14] += -tr.d_s * is2_s * sums[A_S_HX];
+    grad[14] += -tr.d_s * is2_s * hx_s;
     grad[15] += is2_s * sums[A_S_QS];
     grad[16] += is2_s * sums[A_S_Q2] - Ks;
   }
@@ -184,9 +190,22 @@ ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr) {
   p.d_s = tr.d_s;
   p.rw = c->slots[chain].rw;
   p.waner = c->slots[chain].waner;
+  p.iw = c->slots[chain].iw;
+  p.cnt = c->slots[chain].cnt;
   return p;
 }
 ChainPar chain_par(const abd_ctx* c, int chain, const double* t) { return chain_par(c, chain, transform(t)); }
+
+ConstrainArgs constrain_args(const abd_ctx* c) {
+  ConstrainArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.pw = c->ignore_pcr ? nullptr : c->pw;
+  a.N = c->N;
+  a.nt = c->nt;
+  a.n_chunks = c->n_chunks;
+  std::memcpy(a.chunk_mask, c->chunk_mask, sizeof a.chunk_mask);
+  return a;
+}
 
 void base_args(const abd_ctx* c, EvalArgs& a) {
   std::memset(&a, 0, sizeof a);
@@ -404,6 +423,8 @@ void free_ctx(abd_ctx* c) {
   for (auto& s : c->slots) {
     if (s.rw) (void)hipFree(s.rw);
     if (s.waner) (void)hipFree(s.waner);
+    if (s.iw) (void)hipFree(s.iw);
+    if (s.cnt) (void)hipFree(s.cnt);
   }
   for (int pi = 1; pi < kMaxPipes; ++pi)
     if (c->pipe[pi].st) (void)hipStreamSynchronize(c->pipe[pi].st);
@@ -498,9 +519,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   c->n_chunks = d->n_splits + 1;
   c->storage = d->storage;
   c->dense = so_s.one_per_cell && so_n.one_per_cell;
-  // the dense kernel addresses the <= 34 gap rows of a chunk with a 32-bit scalar offset (abd_dense.hpp); beyond
-  // ~8 M individuals per GPU the cohort takes the observation-list kernels instead
-  if ((int64_t)N * (d->storage == ABD_STORE_F32 ? 8 : 16) * 34 >= ((int64_t)1 << 32)) c->dense = false;
+  // the dense kernel addresses the gap rows of a piece (up to G of them) with a 32-bit scalar offset (abd_dense.hpp);
+  // beyond 2^28 cells (fp64; 2^29 in fp32 storage) per GPU the cohort takes the observation-list kernels instead
+  if ((int64_t)N * (d->storage == ABD_STORE_F32 ? 8 : 16) * (G + 2) >= ((int64_t)1 << 32)) c->dense = false;
   if (env_int("ABD_FORCE_SPARSE", 0)) c->dense = false;
   c->ignore_pcr = d->pcrpos == nullptr;
   c->n_slots = d->n_chain_slots;
@@ -588,6 +609,8 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   for (auto& s : c->slots) {
     CREATE_TRY(hipMalloc(&s.rw, words * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc(&s.waner, (size_t)N));
+    CREATE_TRY(hipMalloc(&s.iw, words * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc(&s.cnt, 2 * sizeof(long long)));
   }
   c->pipe[0].st = c->stream;
   c->n_pipes = std::max(1, std::min(6, env_int("ABD_PIPES", c->n_pipes)));
@@ -677,6 +700,11 @@ int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_
   dim3 grid((c->N + 255) / 256, c->nt);
   hipLaunchKernelGGL(abd_pack_bits_kernel, grid, dim3(256), 0, c->stream, c->stage_gn, s.rw, c->G, c->N, c->nt);
   HIP_TRY(hipGetLastError());
+  // what the slot keeps beside the raw state: constrained words, sum(i_raw), sum(ab_s_waner)
+  HIP_TRY(hipMemsetAsync(s.cnt, 0, 2 * sizeof(long long), c->stream));
+  hipLaunchKernelGGL(abd_constrain_kernel, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
+                     reinterpret_cast<unsigned long long*>(s.cnt));
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   s.set = true;
   return ABD_OK;
@@ -691,7 +719,8 @@ int abd_flip_discrete(abd_ctx* c, int32_t chain, int64_t flat) {
   HIP_TRY(hipSetDevice(c->device));
   if (int jrc = join_pipes(c)) return jrc;
   ChainSlot& s = c->slots[(size_t)chain];
-  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, s.rw, s.waner, c->G, c->N, flat);
+  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
+                     reinterpret_cast<unsigned long long*>(s.cnt), c->G, flat);
   HIP_TRY(hipGetLastError());
   return ABD_OK;
 }

@@ -1,46 +1,38 @@
-// abd_dense.hpp -- dense-panel evaluation kernel (included by abd_kernels.hpp after the shared helpers).
+// abd_dense.hpp -- dense-panel evaluation kernel (exactly one S and one N reading in every (gap, individual) cell).
 //
 // lane = individual.  The (lane group, gap) plane -- n_lg groups of 64 individuals x G gap rows -- is cut
 // into equal contiguous ranges, one per wave "slot", so every slot walks the same number of gap rows
 // (+-1) whatever N and G are, and the grid is an exact multiple of the CU count.  A range is walked as
-// one or two pieces (it may end one lane group and begin the next); a piece that does not start at gap 0
-// rebuilds its start state per lane from the packed words: constrain on the words (abd.py:640-667), then
-// the reference's dense design (abd.py:258-274) summed over the set bits before the piece with rho^k read
-// from the chain's LDS table.  Inside a piece the responses advance by the recurrence (abd.py:288).
+// one or more pieces (it may end one lane group and begin the next).  Inside a piece the responses advance by the
+// recurrence the reference tests as equivalent (abd.py:277-293); a piece that does not start at gap 0 rebuilds its
+// start state per lane with the reference's dense design (abd.py:258-274) summed over the set bits before the piece,
+// rho^k read from the chain's LDS table.
+//
+// What is read: the two OD panels (gap rows, 1 KiB per wave and antigen), the chain's CONSTRAINED infection words
+// `iw` -- the Deterministic "i" (abd.py:640-667), kept per chain slot and refreshed by whoever rewrites the slot's
+// discrete state (abd_small.hpp: abd_constrain_kernel; the sweep kernels) -- and the vaccination words, 32 gaps at a
+// time; nothing of the integer pre-pass runs here.  sum(i_raw) and sum(ab_s_waner) come from the slot's counters.
 //
 // The 4 waves of a workgroup are CB chains x (4 / CB) neighbouring ranges: with CB = 4 the panel rows
 // they share are fetched from HBM once and served from L1/L2 to the other three.
 //
+// Latency of one launch matters as much as its throughput (a NUTS chain waits for every evaluation, abd.py:922), so
+// the set-up issues every memory access it needs -- range, 2^(j/1024) table, the piece's words, its first gap rows --
+// before it builds the power tables, and the gap rows are prefetched two gaps ahead across the whole piece.
+//
 // The kernel is bound by vector-instruction issue (fp64 instructions issue at half the rate of 32-bit ones),
 // so the gap loop is written for instruction count:
+//   * the chain constants are pre-scaled by c = 1024 b log2(e): t = c (a - x) is fma(-c, x, c a) with
+//     c a = fma(c temp, U, fma(cf, c perm, c init)); the sum for d/db is sum h t (the host divides by c)
 //   * indicator bits -> 0.0 / 1.0 doubles by v_bfe_i32 (scalar bit index) + v_and with the high word of 1.0;
 //     the "exposed so far" flags of perm_response (abd.py:306) are integer ORs of those high words
-//   * e^u = 2^t with 1024 t = 1024 e + j + f: T[j] = 2^(j/1024) from a 1024-entry LDS table, a cubic in f,
+//   * e^u = 2^(t/1024), t = 1024 e + j + f: T[j] = 2^(j/1024) from a 1024-entry LDS table, a cubic in f,
 //     the exponent e added into T's high word; 1 + 2^t is ONE fma (tools/exp2_table.py: 3.5e-16)
 //   * one v_rcp_f64 per cell for both antigens (1/A = B/(AB))
-//   * gap rows are addressed as scalar row base + a constant per-lane offset (no vector address arithmetic)
+//   * gap rows are addressed as scalar row offset + a constant per-lane offset (no vector address arithmetic)
 #pragma once
 
 #include "abd_device.hpp"
-
-
-// bits [g0, g0 + 32) of the packed row, moved to bit 0 (g0 wave-uniform; bits past the row's end read as zero).
-// Every word is visited with a compile-time index (a runtime-indexed register array would go to scratch); the
-// uniform comparisons are scalar branches, the work is one v_alignbit_b32.
-__device__ __forceinline__ uint32_t extract_bits32(const uint64_t w[ABD_MAXT], int g0) {
-  const int idx = g0 >> 5;
-  const uint32_t sh = (uint32_t)g0 & 31u;
-  uint32_t v = 0;
-#pragma unroll
-  for (int q = 0; q < 2 * ABD_MAXT; ++q) {
-    if (q == idx) {
-      const uint32_t lo = (q & 1) ? (uint32_t)(w[q >> 1] >> 32) : (uint32_t)w[q >> 1];
-      const uint32_t hi = q + 1 < 2 * ABD_MAXT ? (((q + 1) & 1) ? (uint32_t)(w[(q + 1) >> 1] >> 32) : (uint32_t)w[(q + 1) >> 1]) : 0u;
-      v = __builtin_amdgcn_alignbit(hi, lo, sh);
-    }
-  }
-  return v;
-}
 
 // One {od, log_dilution} pair of a gap row: buffer load with a scalar row offset and a constant per-lane offset.
 typedef uint32_t abd_u32x4 __attribute__((ext_vector_type(4)));
@@ -64,16 +56,49 @@ __device__ __forceinline__ YX<float> load_yx<float>(const __amdgpu_buffer_rsrc_t
   return r;
 }
 
+// 32 gaps (word q: gaps 32 q .. 32 q + 31) of one individual's packed row.  The panels are [64-gap word][individual]
+// arrays of 64-bit words; base = the panel seen as 32-bit halves (wave-uniform), j2 = 2 x the lane's individual: the
+// address is a scalar base + a 32-bit lane offset, no 64-bit vector arithmetic.
+__device__ __forceinline__ uint32_t word32(const uint32_t* base, uint32_t j2, int q, int N) {
+  const uint32_t* row = base + ((int64_t)(q >> 1) * 2 * N + (q & 1));
+  return row[j2];
+}
+
+// 1 + 2^(t / 1024) for both antigens of a cell, as one_plus_exp2_tab (abd_device.hpp) twice -- written stage by stage for
+// the two independent chains, so that a wave that has its SIMD to itself (a synchronous call, a sampler unit: one wave per
+// SIMD) overlaps their latencies (fp64 results take ~2 issue slots to come back, the table read ~16) instead of walking one
+// chain after the other.  The polynomial's second coefficient is held in a vector register by the caller (c2v): a VOP3 fma
+// takes one scalar operand, and left alone the compiler re-materialises that constant with a v_mov_b64 per evaluation.
+#define ABD_EXP2_C2 0x1.ebfbe033445b4p-23
+__device__ __forceinline__ void one_plus_exp2_pair(double t_n, double t_s, const double* tab /* LDS */, double c2v, double& A,
+                                                   double& B) {
+  const double kf_n = __builtin_rint(t_n), kf_s = __builtin_rint(t_s);
+  const double f_n = t_n - kf_n, f_s = t_s - kf_s;
+  int k_n, k_s;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(k_n) : "v"(kf_n));  // saturating; a C++ cast of an out-of-range double is undefined
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(k_s) : "v"(kf_s));
+  const double T_n = tab[k_n & (ABD_EXP2_TAB - 1)], T_s = tab[k_s & (ABD_EXP2_TAB - 1)];
+  double p_n, p_s;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p_n) : "s"(0x1.c6b08d910ecbdp-35), "v"(f_n), "v"(c2v));  // tools/exp2_table.py 1024 3
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p_s) : "s"(0x1.c6b08d910ecbdp-35), "v"(f_s), "v"(c2v));
+  const int e_n = min(max(k_n >> 10, -1022), 510), e_s = min(max(k_s >> 10, -1022), 510);  // v_med3_i32
+  p_n = fma(p_n, f_n, 0x1.62e42fefa39efp-11);
+  p_s = fma(p_s, f_s, 0x1.62e42fefa39efp-11);
+  p_n = fma(p_n, f_n, 1.0);
+  p_s = fma(p_s, f_s, 1.0);
+  const double Ts_n = __hiloint2double(__double2hiint(T_n) + (e_n << 20), __double2loint(T_n));  // T 2^e: v_lshl_add_u32
+  const double Ts_s = __hiloint2double(__double2hiint(T_s) + (e_s << 20), __double2loint(T_s));
+  A = fma(Ts_n, p_n, 1.0);
+  B = fma(Ts_s, p_s, 1.0);
+}
 
 // Both antigens of one cell at once: the two reciprocals 1/(1+e_n), 1/(1+e_s) come from ONE v_rcp_f64 (quarter
-// rate) of the product -- 1/A = B/(AB), 1/B = A/(AB).  c_n = b_n log2(e) 1024, c_s likewise (wave-uniform).
+// rate) of the product -- 1/A = B/(AB), 1/B = A/(AB).  t_n = 1024 log2(e) b_n (a_n - x_n), t_s likewise.
 template <bool GRAD>
-__device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, double c_n, double d_n, double as, double xs,
-                                             double ys, double c_s, double d_s, const double* tab, double (&acc)[16],
-                                             double& h_n, double& h_s) {
-  const double amx_n = an - xn, amx_s = as - xs;
-  const double A = one_plus_exp2_tab(c_n * amx_n, tab);
-  const double B = one_plus_exp2_tab(c_s * amx_s, tab);
+__device__ __forceinline__ void obs_pair_scaled(double t_n, double yn, double d_n, double t_s, double ys, double d_s,
+                                                const double* tab, double c2v, double (&acc)[16], double& h_n, double& h_s) {
+  double A, B;
+  one_plus_exp2_pair(t_n, t_s, tab, c2v, A, B);
   const double r = rcp_newton(A * B);
   const double s_n = r * B, s_s = r * A;  // logistic / d
   const double q_n = fma(-d_n, s_n, yn), q_s = fma(-d_s, s_s, ys);
@@ -87,8 +112,8 @@ __device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, do
     h_s = fma(-u_s, s_s, u_s);
     acc[A_N_H] += h_n;
     acc[A_S_H] += h_s;
-    acc[A_N_HX] = fma(h_n, amx_n, acc[A_N_HX]);
-    acc[A_S_HX] = fma(h_s, amx_s, acc[A_S_HX]);
+    acc[A_N_HX] = fma(h_n, t_n, acc[A_N_HX]);  // c_n sum h (a - x): the host divides by c_n (abd_context.hip: assemble)
+    acc[A_S_HX] = fma(h_s, t_s, acc[A_S_HX]);
   }
 }
 
@@ -104,146 +129,275 @@ __device__ __forceinline__ void obs_pair_tab(double an, double xn, double yn, do
 #define ABD_STAMP(k)
 #endif
 
-// The chain's constants as the gap loop wants them (wave-uniform; a VOP3 fma reads at most one scalar operand, so the
-// addends that meet another chain constant live in VGPRs, or every use costs a v_mov_b64).
+// The chain's constants as the gap loop wants them, pre-scaled by c = 1024 log2(e) b (wave-uniform; a VOP3 fma reads at
+// most one scalar operand, so the addends that meet another chain constant live in VGPRs, or every use costs a v_mov_b64).
 struct DenseChain {
-  double rho_n, temp_n, rho_s, init_n, init_s, perm_n, perm_s, d_n, d_s, c_n, c_s;
+  double rho_n, rho_s;
+  double ct_n, cp_n, ci_n, mc_n;  // c_n temp_n, c_n perm_n, c_n init_n (VGPR), -c_n
+  double c_s, cp_s, ci_s, mc_s;   // c_s (unit boosts: abd.py:272), c_s perm_s, c_s init_s (VGPR), -c_s
+  double d_n, d_s;
 };
-__device__ __forceinline__ DenseChain dense_chain(double perm_n, double temp_n, double rho_n, double init_n, double perm_s,
-                                                  double rho_s, double init_s, double b_n, double d_n, double b_s, double d_s) {
+__device__ __forceinline__ DenseChain dense_chain(const ChainPar& p) {
+  // the products are computed by the vector unit (there is no scalar fp64 multiply) and moved back into scalar registers:
+  // left in VGPRs, eight wave-uniform doubles cost the loop 16 registers it does not have
   DenseChain k;
-  k.rho_n = rho_n;
-  k.temp_n = temp_n;
-  k.rho_s = rho_s;
-  k.init_n = to_vgpr(init_n);
-  k.init_s = to_vgpr(init_s);
-  k.perm_n = perm_n;
-  k.perm_s = perm_s;
-  k.d_n = d_n;
-  k.d_s = d_s;
-  k.c_n = b_n * (1.4426950408889634074 * ABD_EXP2_TAB);
-  k.c_s = b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
+  const double c_n = p.b_n * (1.4426950408889634074 * ABD_EXP2_TAB), c_s = p.b_s * (1.4426950408889634074 * ABD_EXP2_TAB);
+  k.rho_n = p.rho_n;
+  k.rho_s = p.rho_s;
+  k.ct_n = readfirstlane_f64(c_n * p.temp_n);
+  k.cp_n = readfirstlane_f64(c_n * p.perm_n);
+  k.ci_n = to_vgpr(c_n * p.init_n);
+  k.mc_n = readfirstlane_f64(-c_n);
+  k.c_s = readfirstlane_f64(c_s);
+  k.cp_s = readfirstlane_f64(c_s * p.perm_s);
+  k.ci_s = to_vgpr(c_s * p.init_s);
+  k.mc_s = readfirstlane_f64(-c_s);
+  k.d_n = p.d_n;
+  k.d_s = p.d_s;
   return k;
 }
 
-// State of one lane's individual at the end of gap g0 - 1 (g0 > 0): the dense design (abd.py:258-274) summed over the
-// exposures before the piece, rho^k from the chain's LDS tables (tab_s: the waning table or the table of ones).
-__device__ __forceinline__ void dense_start_state(const uint64_t (&I)[ABD_MAXT], const uint64_t (&V)[ABD_MAXT], int g0,
-                                                  const double2_t* tab_n, const double2_t* tab_s, double& tn, double& dn,
-                                                  double& ts, double& ds, uint32_t& cfn_hi, uint32_t& cfs_hi) {
+// What a piece (lane group lg, gaps [g0, g1)) needs from memory before its walk can start, requested as early as possible:
+// the words before g0 (start state), the words of its first gaps, its first gap rows.
+#define ABD_SW 8  // 32-gap words per group of the start-state pass (covers g0 <= 256 in one group)
+template <typename R>
+struct PieceLoads {
+  uint32_t seg_i, seg_v, nxt_i, nxt_v;  // words g0 >> 5 and (g0 >> 5) + 1
+  YX<R> en, es, on, os;             // gap rows of the first even and the first odd gap of the piece (N, S antigen)
+  int wj;                           // ab_s_waner of the lane's individual
+};
+
+// Buffer descriptor of one antigen's panel based at row g0 of lane group lg (wave-uniform: built outside divergent code,
+// or every load through it becomes a waterfall loop)
+template <typename R>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t piece_rsrc(const void* panel, int N, int lg, int g0) {
+  const int64_t row0 = ((int64_t)g0 * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(panel)) + row0, 0, -1, 0x00020000);
+}
+
+template <typename R>
+__device__ __forceinline__ void piece_issue_loads(const EvalArgs& a, const __amdgpu_buffer_rsrc_t& rs_n, const __amdgpu_buffer_rsrc_t& rs_s,
+                                                  const uint32_t* ibase, const uint32_t* vbase, const int8_t* waner, int lane, int j,
+                                                  int g0, int g1, PieceLoads<R>& pl) {
+  const int N = a.N;
+  const int q = g0 >> 5, q_end = (g1 - 1) >> 5;
+  // the rows first: they come from the farthest away
+  const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
+  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // G rows of it fit 32 bits (abd_create checks)
+  const int last = g1 - 1 - g0;
+  const int re = min(g0 & 1, last), ro = min((g0 & 1) ^ 1, last);  // row (relative to g0) of the first even / odd gap
+  if (g0 & 1) {
+    pl.on = load_yx<R>(rs_n, lane_off, (uint32_t)ro * rstride);
+    pl.os = load_yx<R>(rs_s, lane_off, (uint32_t)ro * rstride);
+    pl.en = load_yx<R>(rs_n, lane_off, (uint32_t)re * rstride);
+    pl.es = load_yx<R>(rs_s, lane_off, (uint32_t)re * rstride);
+  } else {
+    pl.en = load_yx<R>(rs_n, lane_off, (uint32_t)re * rstride);
+    pl.es = load_yx<R>(rs_s, lane_off, (uint32_t)re * rstride);
+    pl.on = load_yx<R>(rs_n, lane_off, (uint32_t)ro * rstride);
+    pl.os = load_yx<R>(rs_s, lane_off, (uint32_t)ro * rstride);
+  }
+  const uint32_t j2 = 2u * (uint32_t)j;
+  pl.seg_i = word32(ibase, j2, q, N);
+  pl.seg_v = word32(vbase, j2, q, N);
+  pl.nxt_i = pl.nxt_v = 0;
+  if (q < q_end) {
+    pl.nxt_i = word32(ibase, j2, q + 1, N);
+    pl.nxt_v = word32(vbase, j2, q + 1, N);
+  }
+  pl.wj = waner[j];
+}
+
+// words 0 .. ABD_SW - 1 of the constrained infections / the vaccinations, as far as they lie before g0 > 0 (start state)
+__device__ __forceinline__ void state_issue_loads(const uint32_t* ibase, const uint32_t* vbase, uint32_t j2, int N, int g0,
+                                                  uint32_t (&wi)[ABD_SW], uint32_t (&wv)[ABD_SW]) {
+  const int qlast = (g0 - 1) >> 5;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
-    if (t * 64 < g0) {
-      const int rel = g0 - t * 64;  // bits < rel of word t are before the piece
-      const uint64_t below = rel >= 64 ? ~0ull : ((1ull << rel) - 1ull);
-      uint64_t mi = I[t] & below, mv = V[t] & below;
-      if (mi != 0) cfn_hi = 0x3FF00000u;
-      if ((mi | mv) != 0) cfs_hi = 0x3FF00000u;
-      while (mi) {  // per-lane trip count
-        const int b = __builtin_ctzll(mi);
-        mi &= mi - 1;
-        const int idx = g0 - (t * 64 + b);  // = k + 1 with k = (g0 - 1) - r
-        const double2_t pn = tab_n[idx];
-        const double2_t ps = tab_s[idx];
-        tn += pn.x;
-        dn += pn.y;
-        ts += ps.x;
-        ds += ps.y;
+  for (int u = 0; u < ABD_SW; ++u) {
+    wi[u] = wv[u] = 0;
+    if (u <= qlast) {
+      wi[u] = word32(ibase, j2, u, N);
+      wv[u] = word32(vbase, j2, u, N);
+    }
+  }
+}
+
+// State of one lane's individual at the end of gap g0 - 1 (g0 > 0): the dense design (abd.py:258-274) summed over the
+// exposures before the piece, rho^k from the chain's LDS tables: entry e of a table = {rho^(e-1), (e-1) rho^(e-2)}, entry 0
+// = {0, 0}.  Individuals whose S response does not wane (rho_j = 1, abd.py:374) count their exposures instead.
+__device__ __forceinline__ void dense_start_state(uint32_t (&wi)[ABD_SW], uint32_t (&wv)[ABD_SW], const uint32_t* ibase,
+                                                  const uint32_t* vbase, uint32_t j2, int N, int g0, const double2_t* tab_n,
+                                                  const double2_t* tab_s, bool wj, double& tn, double& dn, double& ts, double& ds,
+                                                  uint32_t& cfn_hi, uint32_t& cfs_hi) {
+  const int qlast = (g0 - 1) >> 5;
+  uint32_t any_i = 0, any_v = 0;
+  int cnt = 0;
+  for (int q0 = 0;; q0 += ABD_SW) {
+#pragma unroll
+    for (int u = 0; u < ABD_SW; ++u) {
+      const int q = q0 + u;
+      if (q <= qlast) {                 // wave-uniform
+        const int rel = g0 - q * 32;    // bits < rel of this word are before the piece (rel >= 1)
+        uint32_t mi = wi[u], mv = wv[u];
+        if (rel < 32) {
+          const uint32_t below = (1u << rel) - 1u;
+          mi &= below;
+          mv &= below;
+        }
+        any_i |= mi;
+        any_v |= mv;
+        cnt += __builtin_popcount(mi) + __builtin_popcount(mv);
+        if (__builtin_amdgcn_ballot_w64(mi != 0) != 0) {
+          while (mi) {  // per-lane trip count
+            const int b = __builtin_ctz(mi);
+            mi &= mi - 1;
+            const int idx = rel - b;  // = k + 1 with k = (g0 - 1) - gap of the bit
+            const double2_t pn = tab_n[idx];
+            const double2_t ps = tab_s[idx];
+            tn += pn.x;
+            dn += pn.y;
+            ts += ps.x;
+            ds += ps.y;
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(mv != 0) != 0) {
+          while (mv) {
+            const int b = __builtin_ctz(mv);
+            mv &= mv - 1;
+            const double2_t ps = tab_s[rel - b];
+            ts += ps.x;
+            ds += ps.y;
+          }
+        }
       }
-      while (mv) {
-        const int b = __builtin_ctzll(mv);
-        mv &= mv - 1;
-        const double2_t ps = tab_s[g0 - (t * 64 + b)];
-        ts += ps.x;
-        ds += ps.y;
+    }
+    if (q0 + ABD_SW > qlast) break;
+    // more than ABD_SW words before the piece (g0 > 256): the next group
+#pragma unroll
+    for (int u = 0; u < ABD_SW; ++u) {
+      const int q = q0 + ABD_SW + u;
+      wi[u] = wv[u] = 0;
+      if (q <= qlast) {
+        wi[u] = word32(ibase, j2, q, N);
+        wv[u] = word32(vbase, j2, q, N);
       }
     }
   }
+  if (!wj) {
+    ts = (double)cnt;  // unit boosts that never wane: an infection and a dose in the same gap both count (Q5)
+    ds = 0.0;
+  }
+  cfn_hi = any_i ? 0x3FF00000u : 0u;
+  cfs_hi = (any_i | any_v) ? 0x3FF00000u : 0u;
 }
 
 // Walk gaps [g0, g1) of lane group lg: recurrence form (abd.py:288) + likelihood terms into acc.
 template <typename R, bool GRAD>
-__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const uint64_t (&I)[ABD_MAXT],
-                                           const uint64_t (&V)[ABD_MAXT], int lg, int lane, int g0, int g1, bool wj, double tn,
-                                           double dn, double ts, double ds, uint32_t cfn_hi, uint32_t cfs_hi,
-                                           const double* tab_e2, double (&acc)[16]) {
+__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const __amdgpu_buffer_rsrc_t& rs_n,
+                                           const __amdgpu_buffer_rsrc_t& rs_s, const uint32_t* ibase, const uint32_t* vbase,
+                                           uint32_t j2, PieceLoads<R>& pl, int lane, int g0, int g1, bool wj, double tn, double dn, double ts,
+                                           double ds, uint32_t cfn_hi, uint32_t cfs_hi, const double* tab_e2, double c2v,
+                                           double (&acc)[16]) {
   const int N = a.N;
-  const double rho_n = k.rho_n, temp_n = k.temp_n, init_n = k.init_n, init_s = k.init_s, perm_n = k.perm_n, perm_s = k.perm_s;
-  const double d_n = k.d_n, d_s = k.d_s, c_n = k.c_n, c_s = k.c_s;
+  const double rho_n = k.rho_n, ct_n = k.ct_n, cp_n = k.cp_n, ci_n = k.ci_n, mc_n = k.mc_n;
+  const double c_s = k.c_s, cp_s = k.cp_s, ci_s = k.ci_s, mc_s = k.mc_s, d_n = k.d_n, d_s = k.d_s;
   const double rho_j = wj ? k.rho_s : 1.0;  // abd.py:374
   double hd_s = 0.0;
   const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
-  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // 34 rows of it fit 32 bits (abd_create checks)
+  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);
   const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
-  for (int gc = g0; gc < g1; gc += 32) {  // <= 32 gaps of indicator bits at a time
-    const int len = min(32, g1 - gc);
-    const uint32_t seg_i = extract_bits32(I, gc);
-    const uint32_t seg_v = extract_bits32(V, gc);
-    // gap rows through buffer loads: descriptor base = this chunk's first row of this lane group (scalar), scalar
-    // offset = row within the chunk, vector offset = the lane's constant -- no vector address arithmetic at all
-    const int64_t row0 = ((int64_t)gc * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
-    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.yx_n)) + row0, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.yx_s)) + row0, 0, -1, 0x00020000);
-    auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int gi) { return load_yx<R>(rs, lane_off, (uint32_t)gi * rstride); };
-
-    // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
-    auto step = [&](int gi, const YX<R>& on, const YX<R>& os) {
-      const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, (uint32_t)gi, 1u) & 0x3FF00000u;
-      const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, (uint32_t)gi, 1u) & 0x3FF00000u;
-      const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
-      cfn_hi |= ei_hi;
-      cfs_hi |= ei_hi | ev_hi;
-      dn = fma_s(rho_n, dn, tn);
-      tn = fma_s(rho_n, tn, e_i);
-      ds = fma_v(rho_j, ds, ts);
-      ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
-      const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
-      // mu_n = perm + temp + init   abd.py:341 ; mu_s = perm + tinf + tvac + init   abd.py:389-391
-      const double an = fma(temp_n, tn, fma(cf_n, perm_n, init_n));
-      const double as = fma(cf_s, perm_s, init_s) + ts;
-      double h_n = 0.0, h_s = 0.0;
-      obs_pair_tab<GRAD>(an, (double)on.x, (double)on.y, c_n, d_n, as, (double)os.x, (double)os.y, c_s, d_s, tab_e2, acc,
-                         h_n, h_s);
-      if (GRAD) {
-        acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
-        acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
-        acc[A_N_HD] = fma(h_n, dn, acc[A_N_HD]);
-        acc[A_S_HC] = fma(h_s, cf_s, acc[A_S_HC]);
-        hd_s = fma(h_s, ds, hd_s);
-      }
-    };
-
-    // two row buffers; each is refilled right after the step that consumed it, for the step two gaps on
-    const int last = len - 1;
-    YX<R> n0 = ldrow(rs_n, 0), s0 = ldrow(rs_s, 0);
-    YX<R> n1 = ldrow(rs_n, min(1, last)), s1 = ldrow(rs_s, min(1, last));
-    int gi = 0;
-    for (; gi + 1 < len; gi += 2) {
-      const int ga = min(gi + 2, last), gb = min(gi + 3, last);
-      step(gi, n0, s0);
-      n0 = ldrow(rs_n, ga);
-      s0 = ldrow(rs_s, ga);
-      step(gi + 1, n1, s1);
-      n1 = ldrow(rs_n, gb);
-      s1 = ldrow(rs_s, gb);
+  const int last = g1 - 1 - g0;
+  // gap rows through buffer loads: descriptor base = the piece's first row of this lane group, scalar offset = row
+  // within the piece, vector offset = the lane's constant -- no vector address arithmetic at all
+  auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int g) { return load_yx<R>(rs, lane_off, (uint32_t)min(g - g0, last) * rstride); };
+  int q = g0 >> 5;
+  const int q_end = (g1 - 1) >> 5;
+  uint32_t seg_i = pl.seg_i, seg_v = pl.seg_v;
+  // the next 32 gaps' indicator words arrive while this word's gaps are walked
+  auto next_word = [&]() {
+    seg_i = pl.nxt_i;
+    seg_v = pl.nxt_v;
+    ++q;
+    if (q < q_end) {
+      pl.nxt_i = word32(ibase, j2, q + 1, N);
+      pl.nxt_v = word32(vbase, j2, q + 1, N);
     }
-    if (gi < len) step(gi, n0, s0);
+  };
+
+  // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
+  auto step = [&](int g, const YX<R>& on, const YX<R>& os) {
+    const uint32_t bit = (uint32_t)g & 31u;
+    const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, bit, 1u) & 0x3FF00000u;
+    const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, bit, 1u) & 0x3FF00000u;
+    const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
+    cfn_hi |= ei_hi;
+    cfs_hi |= ei_hi | ev_hi;
+    dn = fma_s(rho_n, dn, tn);
+    tn = fma_s(rho_n, tn, e_i);
+    ds = fma_v(rho_j, ds, ts);
+    ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
+    const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
+    // c mu_n = c (perm + temp + init)   abd.py:341 ; c mu_s = c (perm + tinf + tvac + init)   abd.py:389-391
+    const double t_n = fma(mc_n, (double)on.x, fma(ct_n, tn, fma(cf_n, cp_n, ci_n)));
+    const double t_s = fma(mc_s, (double)os.x, fma(c_s, ts, fma(cf_s, cp_s, ci_s)));
+    double h_n = 0.0, h_s = 0.0;
+    obs_pair_scaled<GRAD>(t_n, (double)on.y, d_n, t_s, (double)os.y, d_s, tab_e2, c2v, acc, h_n, h_s);
+    if (GRAD) {
+      acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
+      acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
+      acc[A_N_HD] = fma(h_n, dn, acc[A_N_HD]);
+      acc[A_S_HC] = fma(h_s, cf_s, acc[A_S_HC]);
+      hd_s = fma(h_s, ds, hd_s);
+    }
+  };
+
+  // two row buffers per antigen, one for the even and one for the odd gaps; each is refilled right after the step that
+  // consumed it, for the gap two on -- across word boundaries, to the end of the piece
+  YX<R> en = pl.en, es = pl.es, on = pl.on, os = pl.os;
+  int g = g0;
+  if (g & 1) {
+    step(g, on, os);
+    on = ldrow(rs_n, g + 2);
+    os = ldrow(rs_s, g + 2);
+    ++g;
+  }
+  for (; g + 1 < g1; g += 2) {
+    if ((g & 31) == 0 && g != g0) next_word();
+    step(g, en, es);
+    en = ldrow(rs_n, g + 2);
+    es = ldrow(rs_s, g + 2);
+    step(g + 1, on, os);
+    on = ldrow(rs_n, g + 3);
+    os = ldrow(rs_s, g + 3);
+  }
+  if (g < g1) {
+    if ((g & 31) == 0 && g != g0) next_word();
+    step(g, en, es);
   }
   acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
 }
 
+// dynamic LDS of the kernel: [CB][2][G+1] power tables, block reduction, 2^(j/1024) table (and at least the scratch of the
+// fused fixed-order sum)
+__host__ __device__ inline size_t abd_dense_lds(int G, int cb) {
+  const size_t need = (size_t)cb * 2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
+                      (size_t)ABD_EXP2_TAB * sizeof(double);
+  const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
+  return need > fin ? need : fin;
+}
+
 template <typename R, int CB, bool GRAD>
-__global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
-  // LDS: [CB][2][G+1] power tables, [G+1] ones table, block reduction, 2^(j/1024) table
+#ifndef ABD_DENSE_MINW
+#define ABD_DENSE_MINW 4
+#endif
+__global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
+  static_assert(CB * ABD_NOUT <= 64, "the own-sum hand-off needs every partial row of the workgroup stored by wave 0");
   extern __shared__ __align__(16) unsigned char smem[];
-  const int G = a.G, N = a.N, nt = a.nt;
+  const int G = a.G, N = a.N;
   const int tstride = G + 1;
-  double2_t* tabs = reinterpret_cast<double2_t*>(smem);
-  double2_t* tab_ones = tabs + CB * 2 * tstride;
-  double* red = reinterpret_cast<double*>(tab_ones + tstride);  // [WAVES][ABD_NOUT]
-  double* tab_e2 = red + ABD_WAVES_PER_BLOCK * ABD_NOUT;           // [ABD_EXP2_TAB] 2^(j/1024)
+  double2_t* tabs = reinterpret_cast<double2_t*>(smem);              // [CB][2][G+1]
+  double* red = reinterpret_cast<double*>(tabs + CB * 2 * tstride);  // [WAVES][ABD_NOUT]
+  double* tab_e2 = red + ABD_WAVES_PER_BLOCK * ABD_NOUT;             // [ABD_EXP2_TAB] 2^(j/1024)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -255,8 +409,8 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   const ChainPar& p = a.ch[cbase + c];
 
   // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2: give every XCD one contiguous
-  // eighth of the plane, so that the ~G/rows-per-range neighbouring ranges that re-read one lane group's packed
-  // words (and the rows shared at range borders) find them in their own L2 instead of fetching them again.
+  // eighth of the plane, so that the neighbouring ranges that re-read one lane group's packed words (and the rows
+  // shared at range borders) find them in their own L2 instead of fetching them again.
   // blk = this workgroup's position in range order (a bijection of blockIdx.x for any grid size).
   ABD_STAMP(0);
   const int nblk = (int)gridDim.x;
@@ -271,34 +425,61 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
     __syncthreads();  // the scratch becomes the power tables
   }
 
-  // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows} from the table the
-  // host built for this launch shape (abd_capi.hip: range_table) -- the 64-bit divisions that cut the plane into equal
-  // ranges cost ~700 scalar and ~80 vector instructions per wave when done here.  The first 16 ranges of every grid row
-  // (the workgroups that may carry a fused sum; one range per workgroup only: CB == 4) are fin_rows shorter, the
-  // others share the difference.  The split depends only on (grid.x, CB), never on the chains of the launch or on
-  // whether a sum is actually carried, so results are bit-identical either way.
-  const int r = blk * NSUB + sub;
-  const int4 rt = reinterpret_cast<const int4*>(a.range_tab)[r];
-  int lg = rt.x, g0 = rt.y, rows_left = rt.z;
-  const bool has_work = rows_left > 0;
-  const int g0_first = has_work ? g0 : 0;
-
-  ABD_STAMP(1);
-  // one wave per chain fills that chain's two power tables, the last wave the ones table.  Only a piece
-  // that starts inside an individual's gaps reads them, and only entries up to its start gap.
-  const int n_entries = CB == ABD_WAVES_PER_BLOCK ? g0_first + 1 : tstride;
-  // the 2^(j/1024) table is requested first and stored last: its loads are in flight while the power tables are built
+  // the 2^(j/1024) table is requested first and stored last: its loads are in flight while everything else is set up
   double e2v[ABD_EXP2_TAB / ABD_BLOCK];
 #pragma unroll
   for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) e2v[q] = a.exp2_tab[q * ABD_BLOCK + tid];
-  if (NSUB >= 2) {  // a chain has two or four waves in this workgroup: one fills its rho_n table, another its rho_s table
-    if (sub == 0) fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
-    if (sub == 1) fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
-  } else {
-    fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
-    fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
+
+  // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows} from the table the
+  // host built for this launch shape (abd_eval.hip: range_table).  The first 16 ranges of every grid row (the workgroups
+  // that may carry a fused sum; one range per workgroup only: CB == 4) are fin_rows shorter, the others share the
+  // difference.  The split depends only on (grid.x, CB), never on the chains of the launch or on whether a sum is
+  // actually carried, so results are bit-identical either way.
+  const int4* rtab = reinterpret_cast<const int4*>(a.range_tab) + (int64_t)blk * NSUB;
+  const int4 rt = rtab[sub];
+  int lg = rt.x, g0 = rt.y, rows_left = rt.z;
+  // power-table entries this workgroup reads: up to the largest start gap of its ranges
+  int n_entries = rows_left > 0 ? g0 + 1 : 0;
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s)
+    if (NSUB > 1 && s != sub) {
+      const int4 o = rtab[s];
+      n_entries = max(n_entries, o.z > 0 ? o.y + 1 : 0);
+    }
+  ABD_STAMP(1);
+
+  // the first piece's memory accesses go out before the tables are built
+  const uint32_t* vbase = reinterpret_cast<const uint32_t*>(a.vw);
+  const uint32_t* ibase = reinterpret_cast<const uint32_t*>(p.iw);
+  PieceLoads<R> pl;
+  int g1 = min(G, g0 + rows_left);
+  int j = lg * 64 + lane;
+  // lanes past the last individual (only the last lane group has any) sit their piece out: EXEC masks them, so
+  // they neither load nor contribute and the residuals need no 0/1 guard factor
+  uint32_t wi[ABD_SW], wv[ABD_SW];  // only a range's first piece can start inside an individual's gaps
+  const bool first_inside = rows_left > 0 && j < N && g0 > 0;
+  __amdgpu_buffer_rsrc_t rs_n = piece_rsrc<R>(a.yx_n, N, lg, g0), rs_s = piece_rsrc<R>(a.yx_s, N, lg, g0);
+  if (rows_left > 0 && j < N) piece_issue_loads<R>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
+  if (first_inside) state_issue_loads(ibase, vbase, 2u * (uint32_t)j, N, g0, wi, wv);
+  // sum(i_raw), sum(ab_s_waner) of the chain: kept with the slot's discrete state (Bernoulli(i_raw | p) is on the RAW
+  // matrix, abd.py:427; Q2); the first range of a chain carries them into the sums
+  long long n1 = 0, m1 = 0;  // (kept as integers in scalar registers until the walk is over)
+  if (blk == 0 && sub == 0) {
+    n1 = p.cnt[0];
+    m1 = p.cnt[1];
   }
-  if (wave == ABD_WAVES_PER_BLOCK - 1) fill_ones_table_wave(tab_ones, n_entries, lane);
+
+  // one wave per table: with CB = 4 every wave fills its chain's two tables (one range per workgroup: entries up to its
+  // start gap), with CB = 2 one each, with CB = 1 waves 0 and 1
+  if (n_entries > 1) {
+    if (NSUB >= 2) {
+      if (sub == 0) fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
+      if (sub == 1) fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
+    } else {
+      fill_pow_table_wave(tabs + (c * 2 + 0) * tstride, p.rho_n, n_entries, lane);
+      fill_pow_table_wave(tabs + (c * 2 + 1) * tstride, p.rho_s, n_entries, lane);
+    }
+  }
   ABD_STAMP(2);
 #pragma unroll
   for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) tab_e2[q * ABD_BLOCK + tid] = e2v[q];
@@ -306,59 +487,46 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
 
   double acc[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+  for (int k = 0; k < ABD_NACC; ++k) acc[k] = 0.0;
 
-  const DenseChain kc = dense_chain(p.perm_n, p.temp_n, p.rho_n, p.init_n, p.perm_s, p.rho_s, p.init_s, p.b_n, p.d_n, p.b_s, p.d_s);
+  const DenseChain kc = dense_chain(p);
+  const double c2v = to_vgpr(ABD_EXP2_C2);
   const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
-  const double2_t* tab_sw = tabs + (c * 2 + 1) * tstride;
+  const double2_t* tab_s = tabs + (c * 2 + 1) * tstride;
   __syncthreads();
   ABD_STAMP(4);
 
-  for (; rows_left > 0; ++lg, g0 = 0) {
+  // state at the end of gap g0 - 1 of the first piece: the dense design (abd.py:258-274) summed over earlier exposures
+  double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
+  uint32_t cfn_hi = 0, cfs_hi = 0;                 // exposure-so-far flags (abd.py:306): high word of 0.0 / 1.0
+  ABD_STAMP(5);
+  if (first_inside)
+    dense_start_state(wi, wv, ibase, vbase, 2u * (uint32_t)j, N, g0, tab_n, tab_s, pl.wj != 0, tn, dn, ts, ds, cfn_hi, cfs_hi);
+  ABD_STAMP(6);
+
+  while (rows_left > 0) {
     // ---- one piece: lane group lg, gaps [g0, g1) ----
-    const int g1 = min(G, g0 + rows_left);
     rows_left -= g1 - g0;
-    // lanes past the last individual (only the last lane group has any) sit the piece out: EXEC masks them, so
-    // they neither load nor contribute and the residuals need no 0/1 guard factor
-    const int j = lg * 64 + lane;
-    if (j < N) {
-
-    // packed indicator rows of this lane's individual; constrain (abd.py:640-667)
-    uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
-#pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
-      V[t] = P[t] = Rw[t] = 0;
-      if (t < nt) {
-        V[t] = a.vw[(int64_t)t * N + j];
-        if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
-        Rw[t] = p.rw[(int64_t)t * N + j];
-      }
-    }
-    const bool wj = p.waner[j] != 0;
-    constrain_masks(Rw, P, a, I);
-#ifdef ABD_STAMPS
-    if (I[0] == 0x123456789abcdefull) acc[15] += 1.0;  // keeps the stamp behind the loads
-#endif
-    ABD_STAMP(5);
-    if (g0 == 0) {  // each individual's gap 0 belongs to exactly one piece
-      int n1 = 0;
-#pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) n1 += __builtin_popcountll(Rw[t]);  // Bernoulli(i_raw | p) is on the RAW matrix
-      acc[ABD_NACC] += (double)n1;
-      acc[ABD_NACC + 1] += wj ? 1.0 : 0.0;
-    }
-
-    // state at the end of gap g0 - 1: the dense design (abd.py:258-274) summed over earlier exposures
-    double tn = 0.0, dn = 0.0, ts = 0.0, ds = 0.0;  // U_n, dU_n/drho_n, U_s, dU_s/drho_j
-    uint32_t cfn_hi = 0, cfs_hi = 0;                 // exposure-so-far flags (abd.py:306): high word of 0.0 / 1.0
-    if (g0 > 0) dense_start_state(I, V, g0, tab_n, wj ? tab_sw : tab_ones, tn, dn, ts, ds, cfn_hi, cfs_hi);
-
-    ABD_STAMP(6);
-    dense_walk<R, GRAD>(a, kc, I, V, lg, lane, g0, g1, wj, tn, dn, ts, ds, cfn_hi, cfs_hi, tab_e2, acc);
-    }  // j < N
+    if (j < N)
+      dense_walk<R, GRAD>(a, kc, rs_n, rs_s, ibase, vbase, 2u * (uint32_t)j, pl, lane, g0, g1, pl.wj != 0, tn, dn, ts, ds, cfn_hi, cfs_hi, tab_e2, c2v,
+                          acc);
+    if (rows_left <= 0) break;
+    // the range goes on at gap 0 of the next lane group, from the zero state
+    ++lg;
+    g0 = 0;
+    g1 = min(G, rows_left);
+    j = lg * 64 + lane;
+    tn = dn = ts = ds = 0.0;
+    cfn_hi = cfs_hi = 0;
+    rs_n = piece_rsrc<R>(a.yx_n, N, lg, g0);
+    rs_s = piece_rsrc<R>(a.yx_s, N, lg, g0);
+    if (j < N) piece_issue_loads<R>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
   }
 
   ABD_STAMP(7);
+  acc[ABD_NACC] = lane == 0 ? (double)n1 : 0.0;
+  acc[ABD_NACC + 1] = lane == 0 ? (double)m1 : 0.0;
+  acc[ABD_NACC + 2] = 0.0;
   // ---- reduction: lanes -> wave -> block (LDS) -> per-block partial in global memory ----
   const double tot = wave_reduce16(acc, lane);
   if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
@@ -377,8 +545,10 @@ __global__ __launch_bounds__(ABD_BLOCK, 4) void abd_dense_kernel(const EvalArgs 
   ABD_STAMP(8);
   if (!a.fin_count) return;
 
-  // ---- own fixed-order sum (a sampler unit's launch, ABD_DENSE_OWN_SUM=1): the workgroup that counts in last for a chain
-  // sums that chain's partial rows itself instead of a second launch; hand-off and order as in abd_obs_kernel ----
+  // ---- own fixed-order sum: the workgroup that counts in last for a chain sums that chain's partial rows itself instead of
+  // a second launch.  Hand-off (MI355X guide, "valid forms"): every partial row of this workgroup was stored write-through
+  // (sc1) by wave 0 (CB x 16 <= 64 lanes), wave 0 drains its stores (s_waitcnt vmcnt(0)) and then one lane per chain counts
+  // in with a returning agent-scope add; the workgroup whose add came last re-reads the rows with sc1 loads behind a barrier
   int* flag = reinterpret_cast<int*>(red);  // the block reduction is done with: [CB] flags
   __syncthreads();
   if (wave == 0) {

@@ -148,8 +148,9 @@ __device__ __forceinline__ void fill_ones_table(double2_t* tab, int n_entries, i
 // wave-uniform values (sparse kernel: scalar unit) and on per-lane values (dense kernel).
 //   raw/pcr : words of i_raw / pcrpos, bit b of word t <-> gap 64 t + b
 //   out     : the Deterministic "i"
+template <typename ARGS>  // anything with n_chunks and chunk_mask (EvalArgs, ConstrainArgs)
 __device__ __forceinline__ void constrain_masks(const uint64_t raw[ABD_MAXT], const uint64_t pcr[ABD_MAXT],
-                                                const EvalArgs& a, uint64_t out[ABD_MAXT]) {
+                                                const ARGS& a, uint64_t out[ABD_MAXT]) {
   uint64_t i0[ABD_MAXT];
   if (a.n_chunks <= 1) {
     // OneTimeChunk: where(i_raw + pcrpos > 0, 1, 0)   abd.py:643-647

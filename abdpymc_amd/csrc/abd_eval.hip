@@ -8,7 +8,7 @@ namespace abdi {
 LaunchProfile g_launch_profile;
 
 size_t table_lds_bytes(int G, int cpw, int red_rows, bool exp2_tab = false);
-size_t dense_lds_bytes(int G, int cpw) { return table_lds_bytes(G, cpw, ABD_WAVES_PER_BLOCK, true); }
+size_t dense_lds_bytes(int G, int cpw) { return abd_dense_lds(G, cpw); }
 size_t table_lds_bytes(int G, int cpw, int red_rows, bool exp2_tab) {
   return std::max<size_t>(ABD_FIN_PARTS * ABD_NOUT * sizeof(double),  // finalize scratch of the fused form
                           (size_t)(cpw * 2 + 1) * (G + 1) * sizeof(double2_t) + (size_t)red_rows * ABD_NOUT * sizeof(double) +
@@ -175,7 +175,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     lds = abd_obs_lds_head(c->G);
   } else if (c->dense) {
     blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate ? 1 : 0), n / cpw);
-    lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK, true);
+    lds = abd_dense_lds(c->G, cpw);
   } else {
     blocks = c->blocks_x;
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);

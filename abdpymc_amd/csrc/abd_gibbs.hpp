@@ -215,6 +215,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(p.rw);
   int8_t* waner = const_cast<int8_t*>(p.waner);
+  uint64_t* iw = const_cast<uint64_t*>(p.iw);
+  long long d_n1 = 0, d_m1 = 0;  // changes of sum(i_raw), sum(ab_s_waner) over this wave's individuals
   const int n_dims = G + 1;  // dims 0..G-1: i_raw[g, j]; dim G: ab_s_waner[j]
   unsigned long long n_acc = 0, n_prop = 0;
 
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     }
     bool wj = __builtin_amdgcn_readfirstlane((int)waner[j]) != 0;
     constrain_masks(Rw, P, a, I);
+    int pc0 = wj ? (1 << 16) : 0;  // sum(i_raw) and ab_s_waner of this individual before the sweep
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) pc0 += __builtin_popcountll(Rw[t]);
 
     // ---- random order and transit flags of this individual's dims ----
     for (int d = lane; d < n_dims; d += 64) {
@@ -353,17 +358,31 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       }
     }
 
-    // ---- write the individual's state back ----
+    // ---- write the individual's state back: raw bits, waning flag, and what the slot keeps beside them (the
+    // constrained words the evaluation kernels read, the changes of sum(i_raw) and sum(ab_s_waner)) ----
     if (lane == 0) {
 #pragma unroll
       for (int t = 0; t < ABD_MAXT; ++t)
-        if (t < nt) rw[(int64_t)t * N + j] = Rw[t];
+        if (t < nt) {
+          rw[(int64_t)t * N + j] = Rw[t];
+          iw[(int64_t)t * N + j] = I[t];
+        }
       waner[j] = wj ? 1 : 0;
     }
+    int pc1 = wj ? (1 << 16) : 0;
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) pc1 += __builtin_popcountll(Rw[t]);
+    d_n1 += (pc1 & 0xFFFF) - (pc0 & 0xFFFF);
+    d_m1 += (pc1 >> 16) - (pc0 >> 16);
   }
   if (lane == 0 && (n_acc | n_prop)) {
     atomicAdd(ga.counts + 2 * c + 0, n_acc);
     atomicAdd(ga.counts + 2 * c + 1, n_prop);
+  }
+  if (lane == 0 && (d_n1 | d_m1)) {
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(const_cast<long long*>(p.cnt));
+    atomicAdd(cnt + 0, (unsigned long long)d_n1);  // two's complement: a negative change wraps to the right sum
+    atomicAdd(cnt + 1, (unsigned long long)d_m1);
   }
 }
 

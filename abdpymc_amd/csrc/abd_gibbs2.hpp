@@ -338,6 +338,8 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(cp.rw);
   int8_t* waner = const_cast<int8_t*>(cp.waner);
+  uint64_t* iw = const_cast<uint64_t*>(cp.iw);
+  long long d_n1 = 0, d_m1 = 0;  // changes of sum(i_raw), sum(ab_s_waner) over this wave's individuals
   unsigned long long n_acc = 0, n_prop_total = 0;
   unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
@@ -366,6 +368,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     }
     bool wj = __builtin_amdgcn_readfirstlane((int)waner[j]) != 0;
     const int firstV = first_bit(V);
+    int pc0 = wj ? (1 << 16) : 0;  // sum(i_raw) and ab_s_waner of this individual before the sweep
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) pc0 += __builtin_popcountll(Rw[t]);
 
     // ---- random order of this individual's proposals ----
     // Philox words as abd_gibbs_kernel: word 0 orders the dims (low 9 bits = the dim), word 1 < 0.8 2^32 proposes the
@@ -663,14 +668,28 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     }
     n_prop_total += (unsigned long long)frontier;
 
-    // ---- write the individual's state back ----
+    // ---- write the individual's state back: raw bits, waning flag, and what the slot keeps beside them (the
+    // constrained words the evaluation kernels read, the changes of sum(i_raw) and sum(ab_s_waner)) ----
     if (lane == 0) {
 #pragma unroll
       for (int t = 0; t < ABD_MAXT; ++t)
-        if (t < nt) rw[(int64_t)t * N + j] = Rw[t];
+        if (t < nt) {
+          rw[(int64_t)t * N + j] = Rw[t];
+          iw[(int64_t)t * N + j] = I[t];
+        }
       waner[j] = wj ? 1 : 0;
     }
+    int pc1 = wj ? (1 << 16) : 0;
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) pc1 += __builtin_popcountll(Rw[t]);
+    d_n1 += (pc1 & 0xFFFF) - (pc0 & 0xFFFF);
+    d_m1 += (pc1 >> 16) - (pc0 >> 16);
     __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0 && (d_n1 | d_m1)) {
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(const_cast<long long*>(cp.cnt));
+    atomicAdd(cnt + 0, (unsigned long long)d_n1);  // two's complement: a negative change wraps to the right sum
+    atomicAdd(cnt + 1, (unsigned long long)d_m1);
   }
   if (lane == 0 && (n_acc | n_prop_total)) {
     atomicAdd(ga.counts + 2 * c + 0, n_acc);

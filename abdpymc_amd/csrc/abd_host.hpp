@@ -82,6 +82,10 @@ struct AntigenDev {
 struct ChainSlot {
   uint64_t* rw = nullptr;   // [nt][N] packed i_raw
   int8_t* waner = nullptr;  // [N]
+  // derived from (rw, waner) and kept current by every writer of the slot (abd_set_discrete, abd_flip_discrete, the sweep
+  // kernels): the constrained infections the evaluation kernels read, and {sum(i_raw), sum(ab_s_waner)}
+  uint64_t* iw = nullptr;      // [nt][N] packed i = constrain(i_raw, pcrpos)   abd.py:640-667
+  long long* cnt = nullptr;    // [2]
   bool set = false;
 };
 

@@ -31,13 +31,76 @@ __global__ __launch_bounds__(256) void abd_pack_bits_kernel(const int8_t* __rest
   dst[(int64_t)t * N + j] = w;
 }
 
-__global__ void abd_flip_kernel(uint64_t* rw, int8_t* waner, int G, int N, int64_t flat) {
+// What the integer pre-pass needs besides the words (a 2 KB EvalArgs is not passed for it)
+struct ConstrainArgs {
+  const uint64_t* pw;  // [nt][N] packed pcrpos, nullptr = ignore_pcrpos
+  int32_t N, nt, n_chunks, pad_;
+  uint64_t chunk_mask[3][ABD_MAXT];
+};
+
+// Refresh a chain slot's cached state from its raw discrete state: iw = constrain(rw, pcrpos) (abd.py:640-667) for every
+// individual, cnt[0] += sum(i_raw), cnt[1] += sum(ab_s_waner) (the caller zeroes cnt; integer adds: order-free).
+__global__ __launch_bounds__(256) void abd_constrain_kernel(const ConstrainArgs a, const uint64_t* __restrict__ rw,
+                                                            const int8_t* __restrict__ waner, uint64_t* __restrict__ iw,
+                                                            unsigned long long* cnt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int n1 = 0, m1 = 0;
+  if (j < a.N) {
+    uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) {
+      P[t] = Rw[t] = 0;
+      if (t < a.nt) {
+        Rw[t] = rw[(int64_t)t * a.N + j];
+        if (a.pw) P[t] = a.pw[(int64_t)t * a.N + j];
+        n1 += __builtin_popcountll(Rw[t]);
+      }
+    }
+    constrain_masks(Rw, P, a, I);
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t)
+      if (t < a.nt) iw[(int64_t)t * a.N + j] = I[t];
+    m1 = waner[j] != 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n1 += __shfl_xor(n1, off, 64);
+    m1 += __shfl_xor(m1, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (n1 | m1)) {
+    atomicAdd(cnt + 0, (unsigned long long)n1);
+    atomicAdd(cnt + 1, (unsigned long long)m1);
+  }
+}
+
+// One proposed flip of the resident state (abd_flip_discrete): the bit, its individual's constrained words, the counters
+__global__ void abd_flip_kernel(const ConstrainArgs a, uint64_t* rw, int8_t* waner, uint64_t* iw, unsigned long long* cnt, int G,
+                                int64_t flat) {
+  const int N = a.N;
   const int64_t gn = (int64_t)G * N;
   if (flat < gn) {
     const int64_t g = flat / N, j = flat % N;
-    rw[(g >> 6) * N + j] ^= 1ull << (g & 63);
+    const uint64_t bit = 1ull << (g & 63);
+    const uint64_t w = rw[(g >> 6) * N + j] ^ bit;
+    rw[(g >> 6) * N + j] = w;
+    cnt[0] += (w & bit) ? 1ull : ~0ull;  // +1 / -1
+    uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t) {
+      P[t] = Rw[t] = 0;
+      if (t < a.nt) {
+        Rw[t] = rw[(int64_t)t * N + j];
+        if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
+      }
+    }
+    constrain_masks(Rw, P, a, I);
+#pragma unroll
+    for (int t = 0; t < ABD_MAXT; ++t)
+      if (t < a.nt) iw[(int64_t)t * N + j] = I[t];
   } else {
-    waner[flat - gn] ^= 1;
+    const int8_t w = waner[flat - gn] ^ 1;
+    waner[flat - gn] = w;
+    cnt[1] += w ? 1ull : ~0ull;
   }
 }
 

@@ -37,6 +37,11 @@ struct ChainPar {
   double b_s, d_s;
   const uint64_t* rw;   // [nt][N] packed i_raw of the chain
   const int8_t* waner;  // [N]
+  // kept with the slot's discrete state and refreshed by whoever rewrites it (abd_small.hpp: abd_constrain_kernel,
+  // abd_flip_kernel; the sweep kernels): the CONSTRAINED infections i = constrain(i_raw, pcrpos) (abd.py:640-667), packed
+  // like rw, and {sum(i_raw), sum(ab_s_waner)}
+  const uint64_t* iw;
+  const long long* cnt;
 };
 
 struct EvalArgs {

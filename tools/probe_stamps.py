@@ -21,8 +21,11 @@ from abdpymc_amd._native import Context  # noqa: E402
 C_ = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+BLOCKS = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # grid of the synchronous launch (0: the library's)
 sc = synthetic.make_cohort(N, G)
 ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C_)
+if BLOCKS:
+    ctx.set_launch_config(blocks=BLOCKS)
 for c in range(C_):
     ctx.set_discrete(c, *synthetic.make_chain_state(N, G, c))
 th = np.stack([synthetic.make_thetas(G, 40, c) for c in range(C_)], axis=1)

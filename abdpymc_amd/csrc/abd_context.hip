@@ -23,52 +23,6 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error() { return g_err.c_str(); }
 void set_error(const std::string& msg) { g_err = msg; }
 
-inline double sigmoid(double t) { return 1.0 / (1.0 + std::exp(-t)); }
-inline double softplus(double t) { return std::max(t, 0.0) + std::log1p(std::exp(-std::fabs(t))); }
-
-Transformed transform(const double* t) {
-  Transformed c;
-  c.p = sigmoid(t[0]);
-  c.perm_n = std::exp(t[1]);
-  c.temp_n = std::exp(t[2]);
-  c.rho_n = sigmoid(t[3]);
-  c.init_n = t[4];
-  c.perm_s = std::exp(t[5]);
-  c.rho_s = sigmoid(t[6]);
-  c.q = sigmoid(t[7]);
-  c.tinf = std::exp(t[8]);
-  c.tvac = std::exp(t[9]);
-  c.init_s = t[10];
-  // b = 0 (a flat curve) is replaced by the smallest scale that keeps c = 1024 log2(e) b a normal number: the logistic
-  // term is 1/2 to the last bit either way, and the dense kernel's sum for d/db, which it returns scaled by c, stays defined
-  c.b_n = t[11] == 0.0 ? 1e-300 : t[11];
-  c.d_n = t[12];
-  c.sig_n = std::exp(t[13]);
-  c.b_s = t[14] == 0.0 ? 1e-300 : t[14];
-  c.d_s = t[15];
-  c.sig_s = std::exp(t[16]);
-  return c;
-}
-
-// Everything transcendental that one theta needs on the host -- the backward transforms and the softplus pairs of the four
-// logit-transformed variables -- computed once, when the evaluation is QUEUED (the host is ahead of the device then), so
-// that fetching a result is a few dozen multiply-adds (at config 3 the fetch of a region's results was 4 % of the region).
-HostTerms prepare(const double* t) {
-  HostTerms h;
-  h.tr = transform(t);
-  const int k4[4] = {0, 3, 6, 7};
-  for (int q = 0; q < 4; ++q) {
-    h.L0[q] = -softplus(-t[k4[q]]);
-    h.L1[q] = -softplus(t[k4[q]]);
-  }
-  return h;
-}
-
-// Priors + transform log-Jacobians in closed form, and their gradient.
-//   p ~ Beta(1, G-1), i_raw ~ Bernoulli(p)                         abd.py:424-427
-//   ab_n_perm/temp ~ Gamma, ab_n_rho ~ Beta(10,1), ab_n_init ~ N  abd.py:329-340
-//   ab_s_* likewise, ab_s_waner ~ Bernoulli(p_waner)               abd.py:367-388
-//   it_*_b ~ N(-1,.5), it_*_d ~ N(2,.5), it_*_sigma ~ Exp(1)       abd.py:464-467
 // theta-independent part of the priors: -lnB(1, G-1) - 2 lnB(10, 1) + sum over the Gammas of
 // alpha log beta - lgamma(alpha) + the Normals' -log sd - 1/2 log 2 pi (14 lgamma calls otherwise made per
 // evaluation)
@@ -85,94 +39,22 @@ double prior_constant(int G) {
   return v;
 }
 
-double priors(const HostTerms& h, const double* t, int G, double cells, double n1, double N, double m1, double* g /*17 or null*/,
-              double prior_const) {
-  double lp = prior_const;
-  if (g) std::fill(g, g + ABD_N_THETA, 0.0);
-  auto gamma_ab = [](double mu, double sd, double& a, double& b) {
-    a = mu * mu / (sd * sd);
-    b = mu / (sd * sd);
-  };
-  {  // theta0
-    const double L0 = h.L0[0], L1 = h.L1[0], p = h.tr.p;
-    const double bm1 = (double)(G - 1) - 1.0;
-    lp += (bm1 == 0.0 ? 0.0 : bm1 * L1) + L0 + L1 + n1 * L0 + (cells - n1) * L1;
-    if (g) g[0] = (1.0 + n1) * (1.0 - p) - p * (bm1 + 1.0 + (cells - n1));
-  }
-  const int gk[5] = {1, 2, 5, 8, 9};
-  const double gmu[5] = {2.0, 1.0, 2.0, 1.0, 1.0};
-  for (int q = 0; q < 5; ++q) {
-    double al, be;
-    gamma_ab(gmu[q], 0.5, al, be);
-    const double gx[5] = {h.tr.perm_n, h.tr.temp_n, h.tr.perm_s, h.tr.tinf, h.tr.tvac};  // exp(t[1]), [2], [5], [8], [9]
-    const double x = gx[q];
-    lp += al * t[gk[q]] - be * x;
-    if (g) g[gk[q]] = al - be * x;
-  }
-  for (int k : {3, 6}) {
-    const double L0 = h.L0[k == 3 ? 1 : 2], L1 = h.L1[k == 3 ? 1 : 2], r = k == 3 ? h.tr.rho_n : h.tr.rho_s;
-    lp += 9.0 * L0 + L0 + L1;
-    if (g) g[k] = 10.0 * (1.0 - r) - r;
-  }
-  {
-    const double L0 = h.L0[3], L1 = h.L1[3], q = h.tr.q;
-    lp += L0 + L1 + m1 * L0 + (N - m1) * L1;
-    if (g) g[7] = (1.0 + m1) * (1.0 - q) - q * (1.0 + (N - m1));
-  }
-  const int nk[6] = {4, 10, 11, 12, 14, 15};
-  const double nmu[6] = {-2.0, -2.0, -1.0, 2.0, -1.0, 2.0};
-  const double nsd[6] = {1.0, 1.0, 0.5, 0.5, 0.5, 0.5};
-  for (int q = 0; q < 6; ++q) {
-    const double z = (t[nk[q]] - nmu[q]) / nsd[q];
-    lp += -0.5 * z * z;
-    if (g) g[nk[q]] = -z / nsd[q];
-  }
-  for (int k : {13, 16}) {
-    const double x = k == 13 ? h.tr.sig_n : h.tr.sig_s;
-    lp += -x + t[k];
-    if (g) g[k] = -x + 1.0;
-  }
-  return lp;
+ModelSizes model_sizes(const abd_ctx* c) {
+  ModelSizes m;
+  m.G = c->G;
+  m.dense = c->dense ? 1 : 0;
+  m.N = (double)c->N;
+  m.cells = (double)c->G * (double)c->N;
+  m.Kn = (double)c->n.K;
+  m.Ks = (double)c->s.K;
+  m.prior_const = c->prior_const;
+  return m;
 }
 
-// Combine the device sums of one chain with the host-side terms.  The device accumulates
-//   Q2 = sum q^2, H.. = sums of h' = q s (1 - s), QS = sum q s   with q = od - d s   (abd_kernels.hpp)
-// so  ll = -1/2 Q2 / sigma^2 - K (log sigma + 1/2 log 2 pi),  d ll / d a_k = -b (d / sigma^2) h'_k.
+// Combine the device sums of one chain with the closed-form terms (abd_terms.hpp)
 void assemble(const abd_ctx* c, const HostTerms& h, const double* t, const double* sums, double* logp, double* grad,
               bool with_priors) {
-  const Transformed& tr = h.tr;
-  const double n1 = sums[ABD_NACC], m1 = sums[ABD_NACC + 1];
-  const double cells = (double)c->G * (double)c->N;
-  double lp = 0.0;
-  if (with_priors)
-    lp = priors(h, t, c->G, cells, n1, (double)c->N, m1, grad, c->prior_const);
-  else if (grad)
-    std::fill(grad, grad + ABD_N_THETA, 0.0);
-  const double Kn = (double)c->n.K, Ks = (double)c->s.K;
-  const double is2_n = 1.0 / (tr.sig_n * tr.sig_n), is2_s = 1.0 / (tr.sig_s * tr.sig_s);
-  lp += -0.5 * is2_n * sums[A_N_Q2] - Kn * (t[13] + 0.5 * kLog2Pi);
-  lp += -0.5 * is2_s * sums[A_S_Q2] - Ks * (t[16] + 0.5 * kLog2Pi);
-  *logp = lp;
-  if (grad) {
-    const double fn = -tr.b_n * tr.d_n * is2_n, fs = -tr.b_s * tr.d_s * is2_s;
-    grad[1] += fn * tr.perm_n * sums[A_N_HC];
-    grad[2] += fn * tr.temp_n * sums[A_N_HU];
-    grad[3] += fn * tr.temp_n * tr.rho_n * (1.0 - tr.rho_n) * sums[A_N_HD];
-    grad[4] += fn * sums[A_N_H];
-    // sum h' (a - x): the dense kernel returns it times c = 1024 log2(e) b (abd_dense.hpp), the list kernels as it is
-    const double kC = 1.4426950408889634074 * ABD_EXP2_TAB;
-    const double hx_n = c->dense ? sums[A_N_HX] / (kC * tr.b_n) : sums[A_N_HX];
-    const double hx_s = c->dense ? sums[A_S_HX] / (kC * tr.b_s) : sums[A_S_HX];
-    grad[11] += -tr.d_n * is2_n * hx_n;
-    grad[12] += is2_n * sums[A_N_QS];
-    grad[13] += is2_n * sums[A_N_Q2] - Kn;
-    grad[5] += fs * tr.perm_s * sums[A_S_HC];
-    grad[6] += fs * tr.rho_s * (1.0 - tr.rho_s) * sums[A_S_HD];
-    grad[10] += fs * sums[A_S_H];
-    grad[14] += -tr.d_s * is2_s * hx_s;
-    grad[15] += is2_s * sums[A_S_QS];
-    grad[16] += is2_s * sums[A_S_Q2] - Ks;
-  }
+  assemble_terms(model_sizes(c), h, t, sums, logp, grad, with_priors);
 }
 
 ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr) {

@@ -32,7 +32,10 @@
 //   * gap rows are addressed as scalar row offset + a constant per-lane offset (no vector address arithmetic)
 #pragma once
 
+#include <cstddef>
+
 #include "abd_device.hpp"
+#include "abd_terms.hpp"
 
 // One {od, log_dilution} pair of a gap row: buffer load with a scalar row offset and a constant per-lane offset.
 typedef uint32_t abd_u32x4 __attribute__((ext_vector_type(4)));
@@ -377,6 +380,119 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
   acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
 }
 
+// ---- leapfrog train (abd_types.hpp: TrainArgs): the launch's last workgroup, wave 0, with the 16 sums in sm[0 .. 15] ----
+// Lane k < 17 owns value variable k: (1) its share of logp and its gradient entry from the sums and the point's closed-form
+// terms (abd_terms.hpp: assemble_lane), logp = the 17 shares added in order; (2) it finishes the leapfrog that led to this
+// point and takes the drift of the next one -- the host's arithmetic (abd_nuts.hpp: feed / stage_leapfrog, diagonal
+// metric), operation by operation and without contraction, so that the host, which repeats it on the record, arrives at
+// the same bits; (3) it transforms the next point and leaves it in slots[next_slot] for the launch queued behind this one;
+// (4) the record goes to mapped host memory, its tag last.  sm: >= 64 doubles of LDS.
+// the point a train launch evaluates: left in device memory by its predecessor, or staged by the host in the kernel
+// arguments (read through the argument segment's address: a lane-indexed access to a by-value struct goes to scratch)
+__device__ __forceinline__ const char* train_kernarg() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  return nullptr;  // (host pass of the compiler: never executed)
+#endif
+}
+__device__ __forceinline__ const TrainPoint* train_point(const TrainArgs& T) {
+  return T.use_slot >= 0 ? T.slots + T.use_slot
+                         : reinterpret_cast<const TrainPoint*>(train_kernarg() + offsetof(EvalArgs, train) + offsetof(TrainArgs, first));
+}
+
+// a successor's first duty (one wave of its first workgroup): the predecessor's record goes to the host -- the
+// predecessor left it beside the point (TrainPoint::prev_*) instead of waiting for its own writes to cross PCIe
+__device__ __forceinline__ void train_forward_record(const TrainArgs& T, int lane) {
+  const TrainPoint* cur = T.slots + T.use_slot;
+  if (lane < ABD_NT) {
+    T.fwd_rec->g[lane] = cur->prev_g[lane];
+    T.fwd_rec->next_theta[lane] = cur->theta[lane];
+    T.fwd_rec->next_p_half[lane] = cur->p_half[lane];
+    if (lane == 0) T.fwd_rec->lp = cur->prev_lp;
+  }
+  __threadfence_system();
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) __hip_atomic_store(&T.fwd_rec->tag, T.fwd_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, int lane) {
+  const TrainArgs& T = a.train;
+  const TrainPoint* cur = train_point(T);
+  const double* inv_mass = reinterpret_cast<const double*>(train_kernarg() + offsetof(EvalArgs, train) + offsetof(TrainArgs, inv_mass));
+  double* lps = sm + 16;  // [17] the variables' shares of logp
+  const int k = lane < ABD_NT ? lane : 0;
+  const int q4 = k == 0 ? 0 : k == 3 ? 1 : k == 6 ? 2 : k == 7 ? 3 : -1;
+  abdi::Transformed tr;  // (field by field: an indexed write would put the struct in scratch)
+  tr.p = cur->tr[0];
+  tr.perm_n = cur->tr[1];
+  tr.temp_n = cur->tr[2];
+  tr.rho_n = cur->tr[3];
+  tr.init_n = cur->tr[4];
+  tr.perm_s = cur->tr[5];
+  tr.rho_s = cur->tr[6];
+  tr.q = cur->tr[7];
+  tr.tinf = cur->tr[8];
+  tr.tvac = cur->tr[9];
+  tr.init_s = cur->tr[10];
+  tr.b_n = cur->tr[11];
+  tr.d_n = cur->tr[12];
+  tr.sig_n = cur->tr[13];
+  tr.b_s = cur->tr[14];
+  tr.d_s = cur->tr[15];
+  tr.sig_s = cur->tr[16];
+  abdi::ModelSizes m;
+  m.G = a.G;
+  m.dense = 1;
+  m.N = (double)a.N;
+  m.cells = (double)a.G * (double)a.N;
+  m.Kn = (double)a.K_n;
+  m.Ks = (double)a.K_s;
+  m.prior_const = T.prior_const;
+  const double tk = cur->theta[k];
+  const double l0 = q4 >= 0 ? cur->L0[q4] : 0.0, l1 = q4 >= 0 ? cur->L1[q4] : 0.0;
+  double lp_k, g_k;
+  abdi::assemble_lane(k, m, tr, tk, cur->tr[k], l0, l1, sm, lp_k, g_k);
+  if (lane < ABD_NT) lps[lane] = lp_k;
+  __builtin_amdgcn_wave_barrier();
+  double lp = 0.0;
+#pragma unroll
+  for (int q = 0; q < ABD_NT; ++q) lp += lps[q];  // every lane, same order
+  if (lane < ABD_NT) {
+    if (T.own_record) {
+      T.rec->g[lane] = g_k;  // the record's first half is on its way while the next point is worked out
+      if (lane == 0) T.rec->lp = lp;
+    }
+    const bool finite = __builtin_isfinite(lp);
+    const double gd = finite ? g_k : 0.0;                              // feed: cur.g = finite ? g1 : 0
+    const double kick = __dmul_rn(__dmul_rn(0.5, T.ve), gd);           // 0.5 * ve * g
+    const double p = __dadd_rn(cur->p_half[lane], kick);               // feed: cur.p = p_half + 0.5 ve g
+    const double ph = __dadd_rn(p, kick);                              // stage_leapfrog: p_half = cur.p + 0.5 ve cur.g
+    const double v = __dmul_rn(inv_mass[lane], ph);                    // velocity, diagonal metric
+    const double t2 = __dadd_rn(tk, __dmul_rn(T.ve, v));               // req_q = cur.q + ve v
+    if (T.own_record) {
+      T.rec->next_theta[lane] = t2;
+      T.rec->next_p_half[lane] = ph;
+    }
+    double tr2, n0, n1;
+    abdi::transform_lane(lane, t2, tr2, n0, n1);
+    TrainPoint* nx = T.slots + T.next_slot;
+    nx->theta[lane] = t2;
+    nx->p_half[lane] = ph;
+    nx->tr[lane] = tr2;
+    if (q4 >= 0) {
+      nx->L0[q4] = n0;
+      nx->L1[q4] = n1;
+    }
+    nx->prev_g[lane] = g_k;  // the successor passes this launch's result on to the host
+    if (lane == 0) nx->prev_lp = lp;
+  }
+  if (!T.own_record) return;
+  __threadfence_system();
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) __hip_atomic_store(&T.rec->tag, T.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // dynamic LDS of the kernel: [CB][2][G+1] power tables, block reduction, 2^(j/1024) table (and at least the scratch of the
 // fused fixed-order sum)
 __host__ __device__ inline size_t abd_dense_lds(int G, int cb) {
@@ -406,7 +522,24 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   const int c = wave % CB;                        // this wave's chain within the block's group
   const int sub = wave / CB;
   const int cbase = blockIdx.y * CB;
-  const ChainPar& p = a.ch[cbase + c];
+  ChainPar p = a.ch[cbase + c];
+  constexpr bool TRAIN = CB == 1 && GRAD;  // leapfrog trains: one chain per launch (abd_types.hpp: TrainArgs)
+  if (TRAIN && a.train.enabled && a.train.use_slot >= 0) {
+    // the point was left in device memory by the launch before this one on the stream
+    const double* tr = a.train.slots[a.train.use_slot].tr;
+    p.perm_n = tr[1];
+    p.temp_n = tr[2];
+    p.rho_n = tr[3];
+    p.init_n = tr[4];
+    p.perm_s = tr[5];
+    p.rho_s = tr[6];
+    p.init_s = tr[10];
+    p.b_n = tr[11];
+    p.d_n = tr[12];
+    p.b_s = tr[14];
+    p.d_s = tr[15];
+    if (a.train.fwd_rec && blockIdx.x == 0 && wave == ABD_WAVES_PER_BLOCK - 1) train_forward_record(a.train, lane);
+  }
 
   // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2: give every XCD one contiguous
   // eighth of the plane, so that the neighbouring ranges that re-read one lane group's packed words (and the rows
@@ -566,8 +699,14 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
 #pragma unroll
   for (int cc = 0; cc < CB; ++cc) {
     if (last[cc]) {
-      finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
-                                         a.fin_out + (int64_t)(cbase + cc) * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.fin_tag);
+      if (TRAIN && a.train.enabled) {
+        sum_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
+                                      reinterpret_cast<double*>(smem), tid);
+        if (wave == 0) train_epilogue(a, reinterpret_cast<double*>(smem), lane);
+      } else {
+        finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
+                                           a.fin_out + (int64_t)(cbase + cc) * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.fin_tag);
+      }
       if (tid == 0) __hip_atomic_store(a.fin_count + cbase + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
     }

@@ -331,8 +331,9 @@ __device__ __forceinline__ void finalize_chain(const double* __restrict__ p, int
 
 // finalize_chain with device-coherent loads of the partial rows (they were written write-through by other workgroups of the
 // SAME kernel, possibly on other XCDs: a plain load could hit a stale line of this XCD's L2).  Same order of additions, same bits.
+// sum_chain_coherent leaves the 16 sums in sm[0 .. 15] (every thread may read them after it returns).
 template <int NT>
-__device__ __forceinline__ void finalize_chain_coherent(const double* p, int n_blocks, double* out, double* sm, int tid, double tag) {
+__device__ __forceinline__ void sum_chain_coherent(const double* p, int n_blocks, double* sm, int tid) {
   const int k = tid % ABD_NOUT;
   for (int part = tid / ABD_NOUT; part < ABD_FIN_PARTS; part += NT / ABD_NOUT) {
     double v = 0.0;
@@ -357,6 +358,10 @@ __device__ __forceinline__ void finalize_chain_coherent(const double* p, int n_b
   __syncthreads();
   if (tid < ABD_NOUT) sm[tid] = t;
   __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ void finalize_chain_coherent(const double* p, int n_blocks, double* out, double* sm, int tid, double tag) {
+  sum_chain_coherent<NT>(p, n_blocks, sm, tid);
   if (tid == 0) {
 #pragma unroll
     for (int q = 0; q < ABD_NOUT - 1; ++q) out[q] = sm[q];

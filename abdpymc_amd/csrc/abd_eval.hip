@@ -154,7 +154,8 @@ int flush_pending(abd_ctx* c) {
 
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
-                  bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr, double* seqp = nullptr) {
+                  bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr, double* seqp = nullptr,
+                  TrainArgs* train = nullptr) {
   // completion tags: the context's sequence, or the caller's own (a sampler unit handled by its own host thread: its
   // result rows are private, so its tags only have to be unique among themselves)
   double& seq = seqp ? *seqp : c->seq;
@@ -199,7 +200,14 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   pp.pbuf ^= 1;
   a.partials = pp.partials[buf];
   // a sampler unit's dense launch sums its own partial rows: no second launch
+  if (train && pp.on)
+    if (int frc = flush_pipe(c, pi)) return frc;  // a train launch sums its own rows: nothing may be pending on its pipe
   const bool fused_sum = c->dense && !lanes && force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on);
+  if (train) {
+    if (!fused_sum || n != 1) return fail(ABD_ERR_STATE, "internal: a leapfrog-train launch needs a dense cohort, one chain and the kernel's own sum");
+    train->tag = seq + 1.0;
+    a.train = *train;
+  }
   if (fused_sum) {
     a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
     a.fin_out = d_out_rows;
@@ -369,6 +377,13 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
     if (rc) return rc;
   }
   return ABD_OK;
+}
+
+// One launch of a leapfrog train (abd_types.hpp: TrainArgs; abd_sampler.hip) for `chain` on pipe `pi`: the launch assembles
+// its own result and leaves it in t->rec under t->tag (set here); nothing is kept in the result slots.
+int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms) {
+  const int32_t ch = chain;
+  return enqueue_group(c, 1, &ch, nullptr, true, c->d_out + (size_t)kSyncSlot * c->n_slots * ABD_NOUT, false, pi, &first_terms, nullptr, t);
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors) {

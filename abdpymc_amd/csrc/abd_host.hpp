@@ -23,9 +23,11 @@
 
 #include "../../include/abd_hip.h"
 #include "abd_types.hpp"
+#include "abd_terms.hpp"
 
 static_assert(ABD_MAX_BATCH == ABD_MAX_BATCH_K, "header / kernel batch size mismatch");
 static_assert(ABD_MAX_GAPS == 64 * ABD_MAXT, "header / kernel gap limit mismatch");
+static_assert(ABD_N_THETA == ABD_NT, "header / kernel value-variable count mismatch");
 
 namespace abdi {
 
@@ -59,7 +61,6 @@ constexpr int kResultSlots = 1024;
 constexpr int kSyncSlot = kResultSlots;  // private rows of the synchronous calls: they never touch a caller's slot
 constexpr int kMaxPipes = 8;             // HIP streams of a context
 constexpr int kMinRows = 4;
-constexpr double kLog2Pi = 1.8378770664093453;  // log(2 pi)
 
 // ABD_SAMPLER_PROFILE: time the host spends inside hipLaunchKernelGGL for evaluation launches and their sums
 struct LaunchProfile {
@@ -87,17 +88,6 @@ struct ChainSlot {
   uint64_t* iw = nullptr;      // [nt][N] packed i = constrain(i_raw, pcrpos)   abd.py:640-667
   long long* cnt = nullptr;    // [2]
   bool set = false;
-};
-
-struct Transformed {
-  double p, perm_n, temp_n, rho_n, init_n, perm_s, rho_s, q, tinf, tvac, init_s;
-  double b_n, d_n, sig_n, b_s, d_s, sig_s;
-};
-
-// see prepare()
-struct HostTerms {
-  Transformed tr;
-  double L0[4], L1[4];  // -softplus(-t), -softplus(t) of theta[0], [3], [6], [7]
 };
 
 struct ResultSlot {
@@ -212,9 +202,7 @@ struct abd_ctx {
 namespace abdi {
 
 // ---- abd_context.hip
-Transformed transform(const double* t);
-HostTerms prepare(const double* t);
-double priors(const HostTerms& h, const double* t, int G, double cells, double n1, double N, double m1, double* g, double prior_const);
+ModelSizes model_sizes(const abd_ctx* c);
 void assemble(const abd_ctx* c, const HostTerms& h, const double* t, const double* sums, double* logp, double* grad, bool with_priors = true);
 ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr);
 ChainPar chain_par(const abd_ctx* c, int chain, const double* t);
@@ -238,6 +226,7 @@ int wait_rows(abd_ctx* c, int slot, int n, double tag, hipStream_t st = nullptr)
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
                  int force_pipe = -1, double* seqp = nullptr);
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true);
+int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms);
 
 // ---- abd_gibbs.hip
 int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,

@@ -333,7 +333,27 @@ struct Nuts {
   // the point whose logp and gradient the transition needs next (valid while active)
   const double* request() const { return req_q; }
 
-  void feed(double lp1, const double* g1) {
+  // leapfrogs the current half still needs after the one that is out for evaluation: the points of a half follow each
+  // other deterministically (stage_leapfrog), so a driver may have the DEVICE take them one after the other (a leapfrog
+  // train, abd_dense.hpp) and feed the results as they arrive; a half that ends early simply never asks for the rest
+  int half_remaining() const { return active ? n_target - n_leaf - 1 : 0; }
+  double signed_step() const { return dir * eps; }
+  const double* staged_momentum() const { return p_half; }
+
+  // next_q / next_p_half: the next point of the half and its half-kicked momentum as the device computed them (the same
+  // operations as stage_leapfrog, diagonal metric); adopted instead of the host's own, so that what the chain records is
+  // exactly what was evaluated
+  void feed(double lp1, const double* g1, const double* next_q = nullptr, const double* next_p_half = nullptr) {
+    const int half_before = depth;
+    feed_(lp1, g1);
+    if (next_q && active && depth == half_before && n_leaf > 0) {
+      std::memcpy(req_q, next_q, sizeof(req_q));
+      std::memcpy(p_half, next_p_half, sizeof(p_half));
+    }
+  }
+
+ private:
+  void feed_(double lp1, const double* g1) {
     const bool finite = std::isfinite(lp1);
     const double ve = dir * eps;
     std::memcpy(cur.q, req_q, sizeof(req_q));
@@ -404,7 +424,6 @@ struct Nuts {
     }
   }
 
- private:
   void start_half() {
     dir = rng.uniform() < 0.5 ? -1 : 1;
     cur = dir < 0 ? left : right;

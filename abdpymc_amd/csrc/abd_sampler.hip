@@ -20,9 +20,119 @@ struct abd_sampler {
   std::vector<double> lp, gr;  // starting points' logp / gradient
   int unit = 1;                // chains per independent unit (sampler_run_units)
   int threads = 1;  // host threads that drive the units (sampler_run_units)
+  // Leapfrog trains (abd_types.hpp: TrainArgs): dense cohort, one chain per unit, diagonal metric.  Every evaluation of such a
+  // sampler is a train launch -- it assembles logp and gradient on the device and leaves the next point of the half for
+  // the launch queued behind it -- and the host keeps up to `lookahead` launches of a half queued ahead of the record it
+  // is waiting for, so a chain's leapfrogs follow each other at the device's pace, not at the host's round trip.
+  bool trains = false;
+  int lookahead = 8;
+  static constexpr int kTrainRing = 32;  // records per unit: > lookahead + 1
+  struct TrainUnit {
+    TrainPoint* slots = nullptr;     // device, [2]
+    TrainRecord* rec_h = nullptr;    // mapped host memory, [kTrainRing] ...
+    TrainRecord* rec_d = nullptr;    // ... as the device sees it
+    uint64_t prod = 0, cons = 0;     // launches queued / records taken (or given up: the rest of a half that ended early)
+    double tags[kTrainRing] = {};
+    int next_slot = 0;               // the slot the last queued launch leaves its successor's point in
+    bool last_own_record = true;     // did the launch queued last write its own record (else its successor passes it on)
+    int queued_in_half = 0;          // launches queued for the half that is being built
+  };
+  std::vector<TrainUnit> tu;
 };
 
 namespace {
+
+void train_free(abd_sampler* s) {
+  for (auto& t : s->tu) {
+    if (t.slots) (void)hipFree(t.slots);
+    if (t.rec_h) (void)hipHostFree(t.rec_h);
+  }
+  s->tu.clear();
+}
+
+int train_alloc(abd_sampler* s) {
+  s->tu.resize((size_t)s->n);
+  for (auto& t : s->tu) {
+    HIP_TRY(hipMalloc(&t.slots, 2 * sizeof(TrainPoint)));
+    HIP_TRY(hipMemset(t.slots, 0, 2 * sizeof(TrainPoint)));
+    HIP_TRY(hipHostMalloc((void**)&t.rec_h, abd_sampler::kTrainRing * sizeof(TrainRecord), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(t.rec_h, 0, abd_sampler::kTrainRing * sizeof(TrainRecord));
+    HIP_TRY(hipHostGetDevicePointer((void**)&t.rec_d, t.rec_h, 0));
+  }
+  return ABD_OK;
+}
+
+// Queue one launch of unit u's train: the point staged by the host (theta, p_half: the first leapfrog of a half, or a
+// plain evaluation with ve = 0), or -- theta == nullptr -- the successor of the launch queued last.
+// own_record: nothing is going to be queued behind this launch that could pass its record on (the last leapfrog of a
+// half, a plain evaluation, no look-ahead): it writes the record itself.
+int train_launch(abd_sampler* s, int u, const double* theta, const double* p_half, double ve, const double* inv_mass, bool own_record) {
+  abd_ctx* c = s->c;
+  abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+  if (t.prod - t.cons >= (uint64_t)abd_sampler::kTrainRing) return fail(ABD_ERR_STATE, "internal: train record ring of unit %d is full", u);
+  TrainArgs ta;
+  std::memset(&ta, 0, sizeof ta);
+  ta.enabled = 1;
+  ta.slots = t.slots;
+  ta.rec = t.rec_d + (t.prod % abd_sampler::kTrainRing);
+  ta.ve = ve;
+  ta.prior_const = c->prior_const;
+  ta.own_record = own_record ? 1 : 0;
+  std::memcpy(ta.inv_mass, inv_mass, sizeof ta.inv_mass);
+  HostTerms ht;
+  std::memset(&ht, 0, sizeof ht);
+  if (theta) {
+    ht = prepare(theta);
+    ta.use_slot = -1;
+    ta.next_slot = 0;
+    std::memcpy(ta.first.theta, theta, sizeof ta.first.theta);
+    if (p_half) std::memcpy(ta.first.p_half, p_half, sizeof ta.first.p_half);
+    std::memcpy(ta.first.tr, &ht.tr, sizeof ta.first.tr);
+    std::memcpy(ta.first.L0, ht.L0, sizeof ta.first.L0);
+    std::memcpy(ta.first.L1, ht.L1, sizeof ta.first.L1);
+  } else {
+    ta.use_slot = t.next_slot;
+    ta.next_slot = t.next_slot ^ 1;
+    if (!t.last_own_record) {  // the predecessor left its record beside the point: this launch passes it on
+      const size_t kp = (size_t)((t.prod - 1) % abd_sampler::kTrainRing);
+      ta.fwd_rec = t.rec_d + kp;
+      ta.fwd_tag = t.tags[kp];
+    }
+  }
+  if (int rc = enqueue_train_launch(c, s->chains[(size_t)u], unit_pipe(c, u), &ta, ht)) return rc;
+  t.tags[t.prod % abd_sampler::kTrainRing] = ta.tag;
+  t.prod += 1;
+  t.next_slot = ta.next_slot;
+  t.last_own_record = own_record;
+  return ABD_OK;
+}
+
+// the first leapfrog of the half chain u's tree is about to build, and as many of its successors as the look-ahead allows
+int train_begin(abd_sampler* s, int u) {
+  abdnuts::Nuts& nu = s->ch[(size_t)u].nuts;
+  abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+  // a launch whose successor is certain to be queued (any but the half's last, given a look-ahead) leaves its record to it
+  const int n_half = nu.half_remaining() + 1;
+  auto own = [&](int j) { return s->lookahead == 0 || j == n_half - 1; };
+  if (int rc = train_launch(s, u, nu.request(), nu.staged_momentum(), nu.signed_step(), nu.inv_mass, own(0))) return rc;
+  t.queued_in_half = 1;
+  const int ahead = std::min(s->lookahead, nu.half_remaining());
+  for (int k = 0; k < ahead; ++k) {
+    if (int rc = train_launch(s, u, nullptr, nullptr, nu.signed_step(), nu.inv_mass, own(t.queued_in_half))) return rc;
+    t.queued_in_half += 1;
+  }
+  return ABD_OK;
+}
+
+// has the oldest outstanding record of unit u landed? (never blocks)
+bool train_ready(const abd_sampler* s, int u) {
+  const abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+  if (t.cons >= t.prod) return false;
+  const size_t k = (size_t)(t.cons % abd_sampler::kTrainRing);
+  if (*(volatile const double*)&t.rec_h[k].tag != t.tags[k]) return false;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return true;
+}
 
 // add chain k's Deterministics at its current point to its running sums (stream st)
 int accumulate_chain(abd_sampler* s, int k, hipStream_t st) {
@@ -88,18 +198,44 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // the starting points through the launch shape the units will use
   rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
   if (!rc && (n + s->unit - 1) / s->unit > 1 && tune_int("ABD_PROBE_QUEUES", 1) != 0) rc = probe_stream_queues(c);
+  s->trains = c->dense && s->unit == 1 && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
+  s->lookahead = std::max(0, std::min(abd_sampler::kTrainRing - 2, tune_int("ABD_TRAIN_LOOKAHEAD", 8)));
+  if (!rc && s->trains) rc = train_alloc(s);
   for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
     const int m = std::min(s->unit, n - lo);
+    if (s->trains) {  // every evaluation of this sampler is assembled on the device (see abd_sampler::trains)
+      const double ones[ABD_N_THETA] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+      rc = train_launch(s, u, theta0 + (size_t)lo * ABD_N_THETA, nullptr, 0.0, ones, true);
+      for (long spin = 0; !rc && !train_ready(s, u); ++spin) {
+        if (spin > 4000000) {
+          __atomic_fetch_add(&c->wait_fallbacks, (int64_t)1, __ATOMIC_RELAXED);
+          if (hipStreamSynchronize(c->pipe[unit_pipe(c, u)].st) != hipSuccess) rc = fail(ABD_ERR_HIP, "hipStreamSynchronize failed");
+          if (!rc && !train_ready(s, u)) rc = fail(ABD_ERR_STATE, "the record of chain %d's starting point never received its tag", chains[lo]);
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      if (!rc) {
+        abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+        const TrainRecord& r = t.rec_h[t.cons % abd_sampler::kTrainRing];
+        s->lp[(size_t)lo] = r.lp;
+        std::memcpy(s->gr.data() + (size_t)lo * ABD_N_THETA, r.g, sizeof(double) * ABD_N_THETA);
+        t.cons += 1;
+      }
+      continue;
+    }
     rc = enqueue_slot(c, kSyncSlot + u, m, chains + lo, theta0 + (size_t)lo * ABD_N_THETA, true, false, unit_pipe(c, u));
     if (!rc) rc = wait_rows(c, kSyncSlot + u, m, c->seq, c->pipe[unit_pipe(c, u)].st);
     if (!rc) rc = fetch_slot(c, kSyncSlot + u, s->lp.data() + lo, s->gr.data() + (size_t)lo * ABD_N_THETA);
   }
   if (rc) {
+    train_free(s);
     delete s;
     return rc;
   }
   for (int k = 0; k < n; ++k) {
     if (!std::isfinite(s->lp[(size_t)k])) {
+      train_free(s);
       delete s;
       return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
     }
@@ -113,6 +249,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     if (e == hipSuccess) e = hipMemsetAsync(s->d_sums, 0, bytes, c->stream);
     if (e != hipSuccess) {
       if (s->d_sums) (void)hipFree(s->d_sums);
+      train_free(s);
       delete s;
       return fail(ABD_ERR_HIP, "sampler sums: %s", hipGetErrorString(e));
     }
@@ -123,6 +260,11 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
 
 void abd_sampler_destroy(abd_sampler* s) {
   if (!s) return;
+  if (!s->tu.empty()) {
+    (void)hipSetDevice(s->c->device);
+    (void)hipDeviceSynchronize();  // launches of a half that ended early may still be on their way
+    train_free(s);
+  }
   if (s->d_sums || s->d_rec_mu || s->d_rec_i8) {
     (void)hipSetDevice(s->c->device);
     (void)hipStreamSynchronize(s->c->stream);
@@ -221,6 +363,10 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   // evaluate the points th[0 .. m) of the unit's chains who[0 .. m)
   auto launch_eval = [&](int u) -> int {
     Unit& un = units[(size_t)u];
+    if (s->trains) {  // a plain evaluation (no leapfrog: ve = 0), assembled on the device like every other of this sampler
+      un.t_queued = std::chrono::steady_clock::now();
+      return train_launch(s, u, un.th.data(), nullptr, 0.0, s->ch[(size_t)u].nuts.inv_mass, true);
+    }
     double* seqp = T_all > 1 ? &c->unit_seq[(size_t)u] : nullptr;
     int rc = enqueue_slot(c, kSyncSlot + u, un.m, un.ids.data(), un.th.data(), true, false, unit_pipe(c, u), seqp);
     if (rc) return rc;
@@ -230,6 +376,23 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   };
   auto launch_tree = [&](int u) -> int {  // the next leapfrog of every tree of the unit that is still growing
     Unit& un = units[(size_t)u];
+    if (s->trains) {
+      abdnuts::Nuts& nu = s->ch[(size_t)u].nuts;
+      abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+      un.m = nu.active ? 1 : 0;
+      if (!nu.active) {
+        t.cons = t.prod;  // what is still queued for a half that ended early is never read
+        return ABD_OK;
+      }
+      un.who[0] = u;
+      un.t_queued = std::chrono::steady_clock::now();
+      if (nu.n_leaf == 0) return train_begin(s, u);  // a new half: its first point is staged on the host
+      if (t.queued_in_half < nu.n_target) {          // the half goes on: keep the look-ahead full
+        t.queued_in_half += 1;
+        return train_launch(s, u, nullptr, nullptr, nu.signed_step(), nu.inv_mass, s->lookahead == 0 || t.queued_in_half == nu.n_target);
+      }
+      return ABD_OK;
+    }
     un.m = 0;
     for (int j = un.lo; j < un.hi; ++j) {
       abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
@@ -244,6 +407,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   };
   auto ready = [&](int u) -> bool {  // have all result rows of the unit's launch landed? (never blocks)
     const Unit& un = units[(size_t)u];
+    if (s->trains) return train_ready(s, u);
     volatile const double* rows = c->h_out + (size_t)(kSyncSlot + u) * c->n_slots * ABD_NOUT;
     for (int k = un.m - 1; k >= 0; --k)
       if (rows[(size_t)k * ABD_NOUT + ABD_NOUT - 1] != un.tag) return false;
@@ -349,7 +513,18 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         ++handled;
         clk::time_point tp0;
         if (profile) tp0 = clk::now();
-        if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) return frc;
+        const double *next_q = nullptr, *next_p_half = nullptr;
+        if (s->trains) {  // the launch assembled its own result: take the record
+          abd_sampler::TrainUnit& t = s->tu[(size_t)u];
+          const TrainRecord& r = t.rec_h[t.cons % abd_sampler::kTrainRing];
+          un.lp[0] = r.lp;
+          std::memcpy(un.gr.data(), r.g, sizeof(double) * ABD_N_THETA);
+          next_q = r.next_theta;  // (the slot is not written again before kTrainRing more launches have been queued)
+          next_p_half = r.next_p_half;
+          t.cons += 1;
+        } else if (int frc = fetch_slot(c, kSyncSlot + u, un.lp.data(), un.gr.data())) {
+          return frc;
+        }
         if (profile) {
           const clk::time_point t1 = clk::now();
           prof_fetch += std::chrono::duration<double>(t1 - tp0).count();
@@ -357,7 +532,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         }
         if (un.state == EVAL) {
           for (int q = 0; q < un.m; ++q)
-            s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA);
+            s->ch[(size_t)un.who[(size_t)q]].nuts.feed(un.lp[(size_t)q], un.gr.data() + (size_t)q * ABD_N_THETA, next_q, next_p_half);
           if (profile) {
             const clk::time_point t1 = clk::now();
             prof_feed += std::chrono::duration<double>(t1 - tp0).count();

@@ -1,7 +1,13 @@
 // abd_types.hpp -- constants and plain structs shared by the device code and its host launchers.
 #pragma once
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else  // plain C++ (tests/native compiles abd_terms.hpp with g++): the qualifiers mean nothing there
+#define __host__
+#define __device__
+#define __forceinline__ inline
+#endif
 #include <stdint.h>
 
 #define ABD_MAXT 4          // 64-gap words per individual (G <= 256)
@@ -42,6 +48,43 @@ struct ChainPar {
   // like rw, and {sum(i_raw), sum(ab_s_waner)}
   const uint64_t* iw;
   const long long* cnt;
+};
+
+// ---- leapfrog trains (abd_dense.hpp: train_epilogue; abd_sampler.hip) ----
+// Inside one half of a NUTS tree doubling the leapfrogs follow each other deterministically (abd_nuts.hpp: stage_leapfrog /
+// feed), so the launch that evaluates point k can itself assemble logp and gradient, finish leapfrog k, take the drift of
+// leapfrog k + 1 and leave point k + 1 where the NEXT launch -- already queued behind it on the same stream -- finds it:
+// the host round trip (result over PCIe, state machine, launch, dispatch: ~12 us) leaves the chain's critical path.
+#define ABD_NT 17  // = ABD_N_THETA (abd_hip.h)
+struct TrainPoint {         // a point of a train as the launch that evaluates it needs it
+  double theta[ABD_NT];
+  double p_half[ABD_NT];    // momentum after the first half kick of the leapfrog that leads to theta
+  double tr[ABD_NT];        // backward transforms of theta (abd_terms.hpp: Transformed, indexed like theta)
+  double L0[4], L1[4];      // -softplus(-t), -softplus(t) of theta[0], [3], [6], [7]
+  // what the launch that left this point found at ITS point: the launch that evaluates this one passes it on to the host
+  // (TrainArgs::fwd_rec), so that no launch of a train waits for its own PCIe writes before the next one may start
+  double prev_lp, prev_g[ABD_NT];
+};
+struct TrainRecord {        // what the host takes from a launch (mapped host memory)
+  double lp;
+  double g[ABD_NT];
+  double next_theta[ABD_NT], next_p_half[ABD_NT];  // the point the launch left for its successor
+  double tag;               // completion tag, written last behind a system-scope fence
+};
+struct TrainArgs {
+  TrainPoint* slots;        // device memory, [2]: written by one launch of the train, read by the next
+  TrainRecord* rec;         // this launch's record
+  double tag;
+  double ve;                // direction x step size of the half
+  double prior_const;       // theta-independent part of the priors (abd_context.hip: prior_constant)
+  int32_t enabled;          // 0: an ordinary evaluation
+  int32_t use_slot;         // >= 0: this launch's point is slots[use_slot]; < 0: `first` below (the host staged it)
+  int32_t next_slot;        // where this launch leaves the next point
+  int32_t own_record;       // 1: this launch writes its own record to `rec` (no successor is going to pass it on)
+  TrainRecord* fwd_rec;     // use_slot >= 0: the predecessor's record, written by this launch from slots[use_slot] ...
+  double fwd_tag;           // ... under the predecessor's tag; nullptr: the predecessor wrote its own
+  double inv_mass[ABD_NT];  // diagonal of M^-1
+  TrainPoint first;
 };
 
 struct EvalArgs {
@@ -89,6 +132,7 @@ struct EvalArgs {
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
   uint64_t chunk_mask[3][ABD_MAXT];
   ChainPar ch[ABD_MAX_BATCH_K];
+  TrainArgs train;  // dense kernel, one chain per launch (abd_sampler.hip)
 };
 
 struct double2_t {

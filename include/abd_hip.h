@@ -295,6 +295,7 @@ int abd_n_pipes(abd_ctx* ctx);
  *   ABD_DENSE_OWN_SUM    1                   0 = a sampler unit's dense launch is summed by a second launch (same bits)
  *   ABD_SAMPLER_THREADS  1 dense / 4 lists   host threads that drive the native sampler's units (<= 8 are used)
  *   ABD_SAMPLER_UNIT     by cohort           chains per independent unit of the native sampler
+ *   ABD_SAMPLER_TRAINS   1                   0 = no leapfrog trains: the host sees every leapfrog before the next is queued
  *   ABD_SAMPLER_PROFILE  0                   1 = abd_sampler_run reports on stderr where the host thread's time went
  *   ABD_GIBBS_STATS      0                   1 = abd_gibbs_sweep reports the dense sweep's scheduler counters on stderr
  * (The Python layer adds ABD_HIP_LIB, the path of this library, and bench.py ABD_DIST_BACKEND.) */

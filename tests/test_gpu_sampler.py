@@ -481,10 +481,12 @@ def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
 def test_dense_unit_launch_that_sums_its_own_partials_gives_the_same_draws(monkeypatch):
     """A sampler unit's dense launch sums its own partial rows (last workgroup in, device-coherent re-read; the default)
     or leaves that to a second launch (ABD_DENSE_OWN_SUM=0): same order of additions, so the same draws bit for bit,
-    with units of one and of two chains."""
+    with units of one and of two chains.  (Leapfrog trains off: they exist only with the own sum and assemble logp on the
+    device -- test_leapfrog_trains_follow_the_host_driven_chain.)"""
     from abdpymc_amd._native import Context
 
     sc = synthetic.make_cohort(700, 130, seed=6)
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "0")
 
     def run(own, unit):
         monkeypatch.setenv("ABD_DENSE_OWN_SUM", own)
@@ -549,3 +551,40 @@ def test_units_on_a_dense_cohort_are_deterministic_and_record_like_a_twin_run():
             np.testing.assert_array_equal(rec["i"][c, k], i_ref)
             lp = O.logp_dlogp(th_b[c, k], rec["i_raw"][c, k], rec["ab_s_waner"][c, k], coh, (17,))[0]
             assert abs(lp - st_b["lp"][c, k]) <= 1e-9 * abs(lp)
+
+
+def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch):
+    """Leapfrog trains (dense cohort, one chain per unit; on by default): inside a half of a tree doubling the launch that
+    evaluates a point assembles logp and gradient on the device, finishes the leapfrog and leaves the next point for the
+    launch queued behind it.  Same transition, same random stream as the host-driven chain; the device's closed forms
+    (exp, log1p) round differently from the host's, so the chains agree to rounding, not bit for bit: the first
+    transitions build the same trees and end within 1e-7 of each other; and a train run repeats itself exactly, whatever
+    the look-ahead did (it depends on timing only)."""
+    from abdpymc_amd._native import Context
+
+    N, G, C = 700, 70, 3
+    sc = synthetic.make_cohort(N, G, seed=9)
+
+    def run(trains):
+        monkeypatch.setenv("ABD_SAMPLER_TRAINS", trains)
+        ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C)
+        for c in range(C):
+            ctx.set_discrete(c, *synthetic.make_chain_state(N, G, c))
+        th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+        smp = ctx.sampler(np.arange(C), th0, tune=50, seed=5, gibbs=True)
+        theta, st = smp.run(12)
+        fb = ctx.wait_fallbacks
+        smp.close()
+        ctx.close()
+        return theta, st, fb
+
+    t_host, s_host, _ = run("0")
+    t_a, s_a, fb_a = run("1")
+    t_b, s_b, fb_b = run("1")
+    assert fb_a == 0 and fb_b == 0
+    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a)
+    assert np.isfinite(t_a).all() and (s_a["n_steps"] >= 1).all()
+    # the first transitions: same trees, same points to rounding (later ones may part ways: a decision on a knife's edge)
+    assert np.array_equal(s_a["n_steps"][:, :3], s_host["n_steps"][:, :3])
+    np.testing.assert_allclose(t_a[:, :3], t_host[:, :3], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(s_a["lp"][:, :3], s_host["lp"][:, :3], rtol=1e-9)

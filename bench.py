@@ -29,6 +29,13 @@ Also in the same JSON line:
   cpu_baseline the plain-C OpenMP restatement (oracle/abd_oracle.c) on the host cores, its 1-thread rate, and B0,
                the reference's own dense (G, G, N) algorithm restated in NumPy (forward only), bounded samples
   sync_evals_per_s   rate seen by a caller that waits for every step (lock-step NUTS over the rank's chains)
+  nuts_evals_per_s   the DELIVERED rate: leapfrogs per second of the native sampler's NUTS over the config's chains
+                     (abd_sampler_run without the sweep, step size settled, >= 1 s or >= 200 iterations): a chain's
+                     leapfrogs follow each other (abd.py:922), so this -- not `value` -- is what a sampling run gets
+  wait_fallbacks     completion-tag waits that fell back to a stream synchronise during the whole run (expect 0)
+
+--config c1 is BASELINE config 1, the reference's default cohort (1 520 individuals x 31 gaps, 35 709 OD readings kept as
+observation lists; tests/golden/default_cohort.npz), 4 chains per call: ~0.9 MB per launch, bound by launches, not bytes.
 """
 import argparse
 import json
@@ -47,10 +54,22 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured: 6.3
 FP64_VECTOR_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (MI355X_MICROARCH.md: half the fp32 vector rate)
 
 CONFIGS = {
+    "c1": dict(n_inds=1520, n_gaps=31, storage="f64", chains=4, cohort="default",
+               name="reference default cohort: 1520 ind x 31 gaps, 35709 OD readings (observation lists), fp64, 4 chains/GPU"),
     "c2": dict(n_inds=1000, n_gaps=60, storage="f64", chains=4, name="synthetic 1000 ind x 60 gaps, fp64, 4 chains/GPU"),
     "c3": dict(n_inds=10000, n_gaps=200, storage="f64", chains=4, name="synthetic 10000 ind x 200 gaps, fp64, 4 chains/GPU"),
     "c5": dict(n_inds=100000, n_gaps=200, storage="f32", chains=1, name="synthetic 100000 ind x 200 gaps, fp32 storage, 1 chain/GPU"),
 }
+
+
+def kernel_sources_sha256():
+    """sha256 over the device sources the PMC counters of profiles/traffic.json were collected on"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("abd_types.hpp", "abd_device.hpp", "abd_dense.hpp", "abd_obs.hpp", "abd_sparse.hpp"):
+        h.update(open(os.path.join(ROOT, "abdpymc_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def _free_port():
@@ -122,7 +141,20 @@ def main():
     splits = tuple(int(s) for s in args.splits.split(",") if s) or None
     K, W = args.steps, args.warmup
 
-    sc = synthetic.make_cohort(N, G)
+    default_cohort = cfg.get("cohort") == "default"
+    if default_cohort:
+        # BASELINE config 1: the reference's own cohort (data/cohort_data, packed as tests/golden/default_cohort.npz) with the
+        # splits abdpymc-infer --split_delta --split_omicron gives it (abd.py:204-221)
+        from types import SimpleNamespace
+
+        z = np.load(os.path.join(ROOT, "tests", "golden", "default_cohort.npz"))
+        m_s = z["is_s"]
+        cols = lambda m: (z["elapsed_months"][m], z["individual_i"][m], z["log_dilution"][m], z["od"][m])  # noqa: E731
+        sc = SimpleNamespace(s_obs=cols(m_s), n_obs=cols(~m_s), vacs=z["vacs"], pcrpos=z["pcrpos"])
+        assert int(z["elapsed_months"].max()) + 1 == G and int(z["individual_i"].max()) + 1 == N
+        splits = splits or (14, 20)
+    else:
+        sc = synthetic.make_cohort(N, G)
     ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=splits, n_chains=C,
                   storage=cfg["storage"], device=device)
     chains = np.arange(C, dtype=np.int32)
@@ -206,10 +238,21 @@ def main():
         w_n += n_r
         return dt
 
+    def all_min(values):
+        if dist is None:
+            return np.asarray(values, dtype=np.float64)
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        if comm_dev:
+            t = t.to(comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.cpu().numpy()
+
     first = float(all_max([region()])[0])
     n_rep = int(min(args.max_repeats, max(3, np.ceil(args.min_seconds / max(first, 1e-9)))))
     w_per_launch, w_n = [], 0
-    times = all_max([region() for _ in range(n_rep)])
+    own_times = np.array([region() for _ in range(n_rep)])
+    times = all_max(own_times)
+    times_fastest_rank = all_min(own_times)  # a straggler shows as a gap between the two
     elapsed = float(np.median(times))
     ctx.kernel_timing(0)
     if not np.all(np.isfinite(lp_all)):
@@ -258,11 +301,14 @@ def main():
     survey_bytes = G * N * (4 * R + 2 + C) + C * N  # byte-per-cell indicator panels
     achieved = alg_bytes / w_avg_s / 1e9
     iso_achieved = alg_bytes / k_avg_s / 1e9
-    prof = {}
+    prof, prof_stale = {}, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp) and not splits and C == CONFIGS[args.config]["chains"]:
+    if os.path.exists(tp) and (not splits or default_cohort) and C == CONFIGS[args.config]["chains"]:
         try:
-            prof = json.load(open(tp)).get(args.config, {})
+            whole = json.load(open(tp))
+            prof = whole.get(args.config, {})
+            # the counters were collected on a build of these sources: anything else and they describe another kernel
+            prof_stale = whole.get("kernel_sources_sha256") != kernel_sources_sha256()
         except Exception:
             prof = {}
     pipe_prof = prof.get("pipe_grid", prof)
@@ -270,7 +316,7 @@ def main():
     if pipe_prof.get("valu_insts_per_launch"):
         insts = float(pipe_prof["valu_insts_per_launch"])
         tf = insts * 64 * 2 / w_avg_s / 1e12  # every vector instruction priced as one fp64 FMA on 64 lanes
-        valu = dict(bound="fp64-valu", insts_per_launch=int(insts), achieved_tflops_equiv=round(tf, 2), peak=FP64_VECTOR_TFLOPS,
+        valu = dict(bound="fp64-valu", stale=bool(prof_stale), insts_per_launch=int(insts), achieved_tflops_equiv=round(tf, 2), peak=FP64_VECTOR_TFLOPS,
                     unit="TFLOP/s", frac=round(tf / FP64_VECTOR_TFLOPS, 4),
                     insts_per_cell_chain=round(insts * 64 / (G * N * C), 2), source=pipe_prof.get("valu_source"),
                     note="vector wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 64 lanes x 2 flop / device "
@@ -278,7 +324,8 @@ def main():
                          "so 1.0 is not reachable and the lever is the instruction count")
     roofline = dict(
         bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-        traffic=pipe_prof.get("hbm_bytes_per_launch"), kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel",
+        traffic=pipe_prof.get("hbm_bytes_per_launch"), traffic_stale=bool(prof_stale) if pipe_prof.get("hbm_bytes_per_launch") else None,
+        kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel",
         kernel_us=round(w_avg_s * 1e6, 3), launches=int(w_n),
         launch_shape=f"stream-ordered, as timed: launches rotate over {ctx.n_pipes} HIP streams on different hardware queues, "
                      "1 workgroup per CU each; device time from HIP events around the K launches of every timed region / K (median)",
@@ -288,8 +335,9 @@ def main():
                       launch_shape="one launch alone on the chip: one stream, full grid (4 workgroups per CU); what a "
                                    "synchronous call runs"),
         valu=valu,
-        note="achieved = algorithmic_bytes_per_launch / kernel_us (the smaller, bit-packed byte count). The working set "
-             "(66 MB at config 3) sits in the 256 MiB Infinity Cache and the kernel is fp64-VALU bound: see roofline.valu",
+        note=("achieved = algorithmic_bytes_per_launch / kernel_us (the smaller, bit-packed byte count). The working set "
+              "(66 MB at config 3) sits in the 256 MiB Infinity Cache and the kernel is fp64-VALU bound: see roofline.valu")
+        if ctx.is_dense else "observation lists: ~0.9 MB per launch, bound by the two launches of an evaluation, not by bytes",
     )
 
     # ---- CPU baselines on the host cores (rank 0, N=1 only) ----
@@ -311,7 +359,10 @@ def main():
                 if el >= budget or n_done >= max_n:
                     return n_done / el, n_done, el
 
-        coh = cohort_of(sc)
+        if default_cohort:
+            coh = O.Cohort(G, N, sc.vacs, sc.pcrpos, O.AntigenObs(*sc.s_obs), O.AntigenObs(*sc.n_obs))
+        else:
+            coh = cohort_of(sc)
         co = c_oracle.COracle(coh, splits)
         # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only thrash
         cores = max(1, min(c_oracle.max_threads(), len(os.sched_getaffinity(0)), int(os.environ.get("ABD_CPU_THREADS", "16"))))
@@ -340,16 +391,9 @@ def main():
                    one_thread=dict(value=round(v_1, 3), unit="evals/s", cores=1, sample=f"{n_1} evals in {el_1:.1f} s, same code, 1 thread"),
                    b0_reference_algorithm=b0)
 
-    # ---- the whole compound step the path serves (informative; N=1 only): NUTS + Gibbs sweep, all chains in lock step
-    compound = None
+    # ---- the rate a sampling run gets, and the compound step around it (rank 0, N=1 only) ----
+    compound, nuts = None, None
     if rank == 0 and world == 1:
-        iters = 12
-        smp = ctx.sampler(chains, thetas[W], tune=iters, seed=1)
-        t3 = time.perf_counter()
-        _, st = smp.run(iters)
-        dt3 = time.perf_counter() - t3
-        smp.close()
-
         def sweep_ms(theta_rows, n=5):
             ts = []
             for k in range(n):
@@ -358,19 +402,53 @@ def main():
                 ts.append((time.perf_counter() - t4) * 1e3)
             return float(np.median(ts))
 
-        sweep_random = sweep_ms(thetas[W])
-        # the same sweep on a converged chain: the simulation's own parameters and infections (almost every proposal is
-        # rejected within a few gaps there; far from the posterior the walks are long)
-        for c in range(C):
-            ctx.set_discrete(c, sc.i_true, np.ones(N, dtype=np.int8))
-        sweep_conv = sweep_ms(np.tile(synthetic.truth_theta(G), (C, 1)))
+        # one sweep of all chains from the bench's FRESH random discrete state (far from the posterior: long walks) --
+        # measured before any sampler run has rewritten it; the first sweep of the five starts from exactly that state
         for c in range(C):
             ctx.set_discrete(c, *states[c])
+        sweep_random = sweep_ms(thetas[W])
+        sweep_conv = None
+        if not default_cohort:
+            # ... and on a converged chain: the simulation's own parameters and infections (almost every proposal is
+            # rejected within a few gaps there)
+            for c in range(C):
+                ctx.set_discrete(c, sc.i_true, np.ones(N, dtype=np.int8))
+            sweep_conv = sweep_ms(np.tile(synthetic.truth_theta(G), (C, 1)))
+        for c in range(C):
+            ctx.set_discrete(c, *states[c])
+        # the compound step, first iterations from the bench's chain states (step size still adapting: short trees)
+        iters = 12
+        smp = ctx.sampler(chains, thetas[W], tune=iters, seed=1)
+        t3 = time.perf_counter()
+        _, st = smp.run(iters)
+        dt3 = time.perf_counter() - t3
+        smp.close()
         compound = dict(chain_iterations_per_s=round(iters * C / dt3, 1), iterations=iters,
                         leapfrogs_per_iteration=round(float(st["n_steps"].mean()), 1), gibbs_sweep_ms=round(sweep_random, 3),
-                        gibbs_sweep_ms_converged_state=round(sweep_conv, 3),
-                        note="abd_sampler_run from the bench's chain states, early tuning (step size still adapting); one sweep = "
-                             f"{C} chains x {G * N + N} binary dims, median of 5, from the bench's random state and from a converged one")
+                        gibbs_sweep_ms_converged_state=None if sweep_conv is None else round(sweep_conv, 3),
+                        note="gibbs_sweep_ms: one sweep of all chains (median of 5) starting from the bench's fresh random discrete state, "
+                             f"before any sampler run ({C} chains x {G * N + N} binary dims); _converged_state: the same on the simulation's own "
+                             "infections and parameters; chain_iterations_per_s: abd_sampler_run, first iterations (step size still adapting)")
+        # NUTS as the native sampler runs it (no sweep): step size settles for 15 iterations, then >= 1 s or >= 200 iterations
+        for c in range(C):
+            ctx.set_discrete(c, *states[c])
+        smp = ctx.sampler(chains, thetas[W], tune=10 ** 6, seed=3, gibbs=False)
+        smp.run(15)
+        n_it = 200  # one call: a run ends with its slowest chain, so short calls would time their idle tails
+        t5 = time.perf_counter()
+        _, st = smp.run(n_it)
+        t_n = time.perf_counter() - t5
+        n_lf = float(st["n_steps"].sum())
+        smp.close()
+        nuts = dict(value=round(n_lf / t_n, 1), chains=C, iterations=n_it, seconds=round(t_n, 3),
+                    leapfrogs_per_iteration_and_chain=round(n_lf / n_it / C, 1),
+                    us_per_leapfrog_of_a_chain=round(t_n / (n_lf / C) * 1e6, 2),
+                    note="leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only; dense "
+                         "cohorts with one chain per unit run leapfrog trains (every launch leaves the next point of the half for the "
+                         "launch queued behind it); each chain reads the OD panels for itself, so the rate is bound by "
+                         "bytes per evaluation, not by the batched kernel's instruction roof")
+        for c in range(C):
+            ctx.set_discrete(c, *states[c])
 
     if rank == 0:
         line = {
@@ -393,11 +471,15 @@ def main():
                           "waited for once; sync_evals_per_s is the rate when every step is waited for",
             "repeats": int(n_rep),
             "region_ms": {"min": round(float(times.min()) * 1e3, 4), "median": round(elapsed * 1e3, 4),
-                          "max": round(float(times.max()) * 1e3, 4), "first": round(first * 1e3, 4)},
+                          "max": round(float(times.max()) * 1e3, 4), "first": round(first * 1e3, 4),
+                          "median_fastest_rank": round(float(np.median(times_fastest_rank)) * 1e3, 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "sync_evals_per_s": round(sync_rate, 1),
+            "nuts_evals_per_s": None if nuts is None else nuts["value"],
+            "nuts": nuts,
             "compound_step": compound,
+            "wait_fallbacks": int(ctx.wait_fallbacks),
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
             "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                 "device_of_rank0": device},

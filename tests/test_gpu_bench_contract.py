@@ -50,6 +50,20 @@ def test_bench_line_has_the_contract_fields():
     assert cb["b0_reference_algorithm"]["value"] > 0
     assert d["value"] > 20 * cb["value"]
     assert d["sync_evals_per_s"] > 0 and d["dist"] is None
+    # the delivered rate (native sampler's NUTS over the config's chains) beside the stream-ordered capacity figure
+    nu = d["nuts"]
+    assert d["nuts_evals_per_s"] == nu["value"] > 1e4 and nu["chains"] == 4
+    assert nu["iterations"] >= 200 or nu["seconds"] >= 1.0
+    assert d["nuts_evals_per_s"] < d["value"]
+    # sweep times on states the note names: fresh random state first, the converged one beside it
+    cs = d["compound_step"]
+    assert cs["gibbs_sweep_ms"] > cs["gibbs_sweep_ms_converged_state"] > 0 and "fresh random" in cs["note"]
+    # no completion-tag wait fell back to a stream synchronise anywhere in the run
+    assert d["wait_fallbacks"] == 0
+    # the PMC-derived entries say whether they were counted on these kernel sources
+    if ro["valu"] is not None:
+        assert isinstance(ro["valu"]["stale"], bool)
+    assert d["region_ms"]["median_fastest_rank"] <= d["region_ms"]["median"]
 
 
 def test_bench_starts_its_own_ranks():
@@ -62,3 +76,26 @@ def test_bench_starts_its_own_ranks():
     assert d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo"
     assert d["gather_ms"] is not None and d["gather_ms"] > 0
     assert d["value"] > 0 and d["cpu_baseline"] is None
+
+
+def test_bench_rehearses_the_drivers_multi_gpu_shape():
+    """`bench.py --gpus 4 --config c3 --steps 20 --warmup 5` as the driver launches it on an 8-GPU node, rehearsed with four
+    ranks sharing this box's one GPU (gloo instead of RCCL): 16 chains in all, one gather of the sample block."""
+    env = {"ABD_DIST_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    d = _run(["--gpus", "4", "--config", "c3", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--max-repeats", "20"], env=env)
+    assert d["n_gpus"] == 4 and d["dist"]["world_size"] == 4 and d["dist"]["backend"] == "gloo"
+    assert d["config"]["total_chains"] == 16 and d["config"]["chains_per_gpu"] == 4
+    assert d["gather_ms"] is not None and d["gather_ms"] > 0
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert 0 < d["region_ms"]["median_fastest_rank"] <= d["region_ms"]["median"]  # per-rank spread: a straggler would show
+
+
+def test_bench_config_1_is_the_references_default_cohort():
+    """BASELINE config 1: the reference's default cohort (observation lists), 4 chains per call."""
+    d = _run(["--config", "c1", "--steps", "50", "--warmup", "10", "--cpu-seconds", "3"])
+    assert d["config"]["n_inds"] == 1520 and d["config"]["n_gaps"] == 31 and d["config"]["splits"] == [14, 20]
+    assert d["roofline"]["kernel"] == "abd_obs_kernel" and 0.5e6 < d["roofline"]["algorithmic_bytes_per_launch"] < 2e6
+    assert d["value"] > 1e4 and d["sync_evals_per_s"] > 1e4 and d["nuts_evals_per_s"] > 1e4
+    assert d["cpu_baseline"]["value"] > 0 and d["wait_fallbacks"] == 0

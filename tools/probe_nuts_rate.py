@@ -31,7 +31,7 @@ if cfg == "default":
 else:
     N, G = {"c2": (1000, 60), "c3": (10000, 200)}[cfg]
     sc = synthetic.make_cohort(N, G)
-    ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C)
+    ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C, storage=os.environ.get("ABD_PROBE_STORAGE", "f64"))
     states = [synthetic.make_chain_state(N, G, c) for c in range(C)]
     th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
 for c in range(C):

@@ -515,6 +515,13 @@ class DiscreteMirror:
     def invalidate(self):
         self._state = None
 
+    def adopt(self, i_raw, waner):
+        """The device holds exactly this state now (e.g. it was just read back after a device sweep): remember it under
+        the slot's current generation without uploading anything."""
+        i_raw, waner = np.asarray(i_raw), np.asarray(waner)
+        self._state = (i_raw.copy(), waner.copy(), i_raw, waner)
+        self._gen = self.ctx.generation(self.chain)
+
     def update(self, i_raw, waner):
         ctx, c = self.ctx, self.chain
         i_raw, waner = np.asarray(i_raw), np.asarray(waner)

@@ -240,3 +240,49 @@ def test_pytensor_op_core_constrained_gradient_and_uploads(test_td):
         prior = O.prior_logp_grad(theta, m.n_gaps, m.n_gaps * m.n_inds, int(ir.sum()), m.n_inds, int(waner.sum()))[0]
         assert abs(val - (joint - prior)) <= 1e-9 * abs(joint)
     m.close()
+
+
+def test_pymc_shaped_step_over_the_device_sweep(test_td):
+    """GibbsSweepStep.astep(point) -> (point, stats), the core of the step that stands in for pm.BinaryGibbsMetropolis
+    (INTEGRATION.md level 2): each call is exactly one abd_gibbs_sweep of the slot at the point's continuous values --
+    same bits as driving Context.gibbs_sweep + get_discrete by hand on a twin context -- and it uploads the discrete
+    state only when the device does not already hold it; NUTS's callable on the same slot then sees the swept state."""
+    import abdpymc_amd
+    from abdpymc_amd.pymc_step import GibbsSweepStep
+
+    coh = _oracle_cohort(test_td)
+    m = abdpymc_amd.model(test_td, splits=(14,))
+    twin = abdpymc_amd.model(test_td, splits=(14,))
+    rng = np.random.default_rng(5)
+    pt = m.initial_point()
+    pt["i_raw"] = (rng.random((m.n_gaps, m.n_inds)) < 0.05).astype(np.int64)
+    theta = m.ravel(pt)
+    step = GibbsSweepStep(m, chain=0, seed=77)
+    fn = m.logp_dlogp_function()
+    twin.ctx.set_discrete(0, pt["i_raw"], pt["ab_s_waner"])
+    for k in range(4):
+        new_pt, stats = step.astep(pt)
+        acc, prop = twin.ctx.gibbs_sweep([0], theta[None], seed=77, sweep=k)
+        i_ref, w_ref = twin.ctx.get_discrete(0)
+        np.testing.assert_array_equal(new_pt["i_raw"], i_ref)
+        np.testing.assert_array_equal(new_pt["ab_s_waner"], w_ref)
+        assert stats == {"accepted": int(acc[0]), "proposed": int(prop[0])} and stats["proposed"] > 0
+        assert new_pt["i_raw"].dtype == pt["i_raw"].dtype and set(new_pt) == set(pt)
+        # the continuous part of the point is passed through untouched
+        assert all(np.array_equal(new_pt[n], pt[n]) for n in m.continuous_value_vars)
+        # NUTS on the same slot: its callable uploads the swept state (the sweep bumped the slot's generation) and
+        # evaluates there
+        fn.set_extra_values(new_pt)
+        want = O.logp_dlogp(theta, new_pt["i_raw"], new_pt["ab_s_waner"], coh, (14,))[0]
+        assert abs(fn(theta)[0] - want) <= RTOL * abs(want)
+        pt = new_pt
+    # handing back exactly what the step returned costs no upload: one at the start, one after each of NUTS's rewrites
+    assert step.mirror.uploads == 4 and step.n_sweeps == 4
+    # ... and none at all when nobody else touches the slot in between
+    solo = GibbsSweepStep(twin, chain=0, seed=1)
+    p2 = dict(pt)
+    for k in range(3):
+        p2, _ = solo.astep(p2)
+    assert solo.mirror.uploads == 1 and solo.mirror.hits == 2
+    m.close()
+    twin.close()

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 N_THETA = 17
-MAX_GAPS = 256
+MAX_GAPS = 512
 STORE_F64, STORE_F32 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

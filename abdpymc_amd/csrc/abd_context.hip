@@ -252,13 +252,13 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
     return ABD_OK;
   }
   std::vector<R> y(std::max<size_t>(K, 1)), x(std::max<size_t>(K, 1));
-  std::vector<uint8_t> g(std::max<size_t>(K, 1));
+  std::vector<uint16_t> g(std::max<size_t>(K, 1));
   std::vector<int32_t> jj(std::max<size_t>(K, 1));
   for (size_t k = 0; k < K; ++k) {
     const int64_t src = so.order[k];
     y[k] = (R)o.od[src];
     x[k] = (R)o.log_dilution[src];
-    g[k] = (uint8_t)o.idx_gap[src];
+    g[k] = (uint16_t)o.idx_gap[src];
     jj[k] = (int32_t)o.idx_ind[src];
   }
   HIP_TRY(hipMalloc(&d.j, jj.size() * sizeof(int32_t)));
@@ -267,8 +267,8 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
   HIP_TRY(hipMalloc(&d.x, x.size() * sizeof(R)));
   HIP_TRY(hipMemcpy(d.y, y.data(), y.size() * sizeof(R), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d.x, x.data(), x.size() * sizeof(R), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&d.g, g.size()));
-  HIP_TRY(hipMemcpy(d.g, g.data(), g.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&d.g, g.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(d.g, g.data(), g.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&d.ptr, so.ptr.size() * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(d.ptr, so.ptr.data(), so.ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return ABD_OK;
@@ -342,7 +342,10 @@ int launch_deterministics(abd_ctx* c, int chain, const double* theta, hipStream_
   a.ch[0] = chain_par(c, chain, theta);
   const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t);
   const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-  hipLaunchKernelGGL(abd_deterministics_kernel, dim3(blocks), dim3(ABD_BLOCK), lds, st, a, out_i, out_mun, out_mus, sums);
+  if (c->nt > ABD_MAXT)
+    hipLaunchKernelGGL(abd_deterministics_kernel<ABD_MAXT_MAX>, dim3(blocks), dim3(ABD_BLOCK), lds, st, a, out_i, out_mun, out_mus, sums);
+  else
+    hipLaunchKernelGGL(abd_deterministics_kernel<ABD_MAXT>, dim3(blocks), dim3(ABD_BLOCK), lds, st, a, out_i, out_mun, out_mus, sums);
   HIP_TRY(hipGetLastError());
   return ABD_OK;
 }
@@ -445,7 +448,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     const int cap = c->n_cu * 8;
     c->ob_n = (int)std::min<int64_t>((d->n.n_obs + ABD_BLOCK - 1) / ABD_BLOCK, cap);
     c->ob_s = (int)std::min<int64_t>((d->s.n_obs + ABD_BLOCK - 1) / ABD_BLOCK, cap);
-    c->ob_c = std::max(1, std::min((N + ABD_BLOCK - 1) / ABD_BLOCK, 64));
+    c->ob_c = 1;  // one workgroup carries the slot's counters (sum(i_raw), sum(ab_s_waner)) into the sums
     // lane per observation unless the lists are so full that a wave per individual keeps its 64 lanes busy
     // for two rounds or more and amortises the constraint pass (measured crossover, tools/bench_sparse.py)
     c->obs_lanes = d->s.n_obs + d->n.n_obs < (int64_t)256 * N;
@@ -584,8 +587,12 @@ int abd_set_discrete(abd_ctx* c, int32_t chain, const int8_t* i_raw, const int8_
   HIP_TRY(hipGetLastError());
   // what the slot keeps beside the raw state: constrained words, sum(i_raw), sum(ab_s_waner)
   HIP_TRY(hipMemsetAsync(s.cnt, 0, 2 * sizeof(long long), c->stream));
-  hipLaunchKernelGGL(abd_constrain_kernel, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
-                     reinterpret_cast<unsigned long long*>(s.cnt));
+  if (c->nt > ABD_MAXT)
+    hipLaunchKernelGGL(abd_constrain_kernel<ABD_MAXT_MAX>, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, constrain_args(c), s.rw,
+                       s.waner, s.iw, reinterpret_cast<unsigned long long*>(s.cnt));
+  else
+    hipLaunchKernelGGL(abd_constrain_kernel<ABD_MAXT>, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, constrain_args(c), s.rw,
+                       s.waner, s.iw, reinterpret_cast<unsigned long long*>(s.cnt));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   s.set = true;
@@ -601,8 +608,12 @@ int abd_flip_discrete(abd_ctx* c, int32_t chain, int64_t flat) {
   HIP_TRY(hipSetDevice(c->device));
   if (int jrc = join_pipes(c)) return jrc;
   ChainSlot& s = c->slots[(size_t)chain];
-  hipLaunchKernelGGL(abd_flip_kernel, dim3(1), dim3(1), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
-                     reinterpret_cast<unsigned long long*>(s.cnt), c->G, flat);
+  if (c->nt > ABD_MAXT)
+    hipLaunchKernelGGL(abd_flip_kernel<ABD_MAXT_MAX>, dim3(1), dim3(1), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
+                       reinterpret_cast<unsigned long long*>(s.cnt), c->G, flat);
+  else
+    hipLaunchKernelGGL(abd_flip_kernel<ABD_MAXT>, dim3(1), dim3(1), 0, c->stream, constrain_args(c), s.rw, s.waner, s.iw,
+                       reinterpret_cast<unsigned long long*>(s.cnt), c->G, flat);
   HIP_TRY(hipGetLastError());
   return ABD_OK;
 }
@@ -686,7 +697,7 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   // indicator panels are bit-packed in 64-gap words: vacs + pcrpos + one i_raw per chain, plus the waner bytes
   const int64_t bits = (int64_t)c->nt * c->N * 8 * (2 + n_chains) + (int64_t)n_chains * c->N;
   if (c->dense) return cells * 4 * R + bits;
-  return (c->s.K + c->n.K) * (2 * R + 1) + 2 * (int64_t)(c->N + 1) * 4 + bits;
+  return (c->s.K + c->n.K) * (2 * R + 2) + 2 * (int64_t)(c->N + 1) * 4 + bits;
 }
 
 }  // extern "C"

@@ -148,26 +148,26 @@ __device__ __forceinline__ void fill_ones_table(double2_t* tab, int n_entries, i
 // wave-uniform values (sparse kernel: scalar unit) and on per-lane values (dense kernel).
 //   raw/pcr : words of i_raw / pcrpos, bit b of word t <-> gap 64 t + b
 //   out     : the Deterministic "i"
-template <typename ARGS>  // anything with n_chunks and chunk_mask (EvalArgs, ConstrainArgs)
-__device__ __forceinline__ void constrain_masks(const uint64_t raw[ABD_MAXT], const uint64_t pcr[ABD_MAXT],
-                                                const ARGS& a, uint64_t out[ABD_MAXT]) {
-  uint64_t i0[ABD_MAXT];
+template <int MT, typename ARGS>  // MT: 64-gap words per individual; ARGS: anything with n_chunks and chunk_mask
+__device__ __forceinline__ void constrain_masks(const uint64_t (&raw)[MT], const uint64_t (&pcr)[MT],
+                                                const ARGS& a, uint64_t (&out)[MT]) {
+  uint64_t i0[MT];
   if (a.n_chunks <= 1) {
     // OneTimeChunk: where(i_raw + pcrpos > 0, 1, 0)   abd.py:643-647
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) i0[t] = raw[t] | pcr[t];
+    for (int t = 0; t < MT; ++t) i0[t] = raw[t] | pcr[t];
   } else {
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) i0[t] = 0;
+    for (int t = 0; t < MT; ++t) i0[t] = 0;
     for (int c = 0; c < a.n_chunks; ++c) {
       // mask_multiple_infections on the chunk: keep the first 1   abd.py:818
       // incorporate_pcrpos: any PCR+ in the chunk replaces the whole chunk column   abd.py:771
       bool has_pcr = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) has_pcr |= (pcr[t] & a.chunk_mask[c][t]) != 0;
+      for (int t = 0; t < MT; ++t) has_pcr |= (pcr[t] & a.chunk_mask[c][t]) != 0;
       bool found = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
+      for (int t = 0; t < MT; ++t) {
         const uint64_t cm = a.chunk_mask[c][t];
         uint64_t r = raw[t] & cm;
         uint64_t first = found ? 0ull : (r & (0ull - r));
@@ -181,7 +181,7 @@ __device__ __forceinline__ void constrain_masks(const uint64_t raw[ABD_MAXT], co
   // lies in the three gaps before it.
   int block_until = 0;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     uint64_t m = i0[t];
     uint64_t keep = 0;
     while (m) {
@@ -417,13 +417,14 @@ struct Resp {
 };
 
 // sum over exposures r <= g of rho^(g-r) (and derivative), literal abd.py:258-274 restricted to set bits.
-__device__ __forceinline__ Resp responses(int g, int tmax, const uint64_t I[ABD_MAXT], const uint64_t V[ABD_MAXT],
+template <int MT>
+__device__ __forceinline__ Resp responses(int g, int tmax, const uint64_t (&I)[MT], const uint64_t (&V)[MT],
                                           const double2_t* tab_n, const double2_t* tab_s) {
   Resp r;
   r.un = r.dn = r.us = r.ds = 0.0;
   bool ci = false, civ = false;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if (t < tmax) {
       const int rel = g - t * 64;  // bits <= rel of this word are exposures at or before g
       const uint64_t le = rel >= 63 ? ~0ull : (rel < 0 ? 0ull : ((2ull << rel) - 1ull));

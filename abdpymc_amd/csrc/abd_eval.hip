@@ -39,7 +39,11 @@ hipError_t launch_dense(int C, bool grad, dim3 grid, size_t lds, hipStream_t st,
 }
 template <typename R, int C>
 hipError_t launch_sparse_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  return grad ? launch_k(abd_sparse_kernel<R, C, true>, grid, lds, st, a) : launch_k(abd_sparse_kernel<R, C, false>, grid, lds, st, a);
+  if (a.nt > ABD_MAXT)  // more than 256 gaps: the kernels that keep an individual's words in registers are built for 8 words too
+    return grad ? launch_k(abd_sparse_kernel<R, C, true, ABD_MAXT_MAX>, grid, lds, st, a)
+                : launch_k(abd_sparse_kernel<R, C, false, ABD_MAXT_MAX>, grid, lds, st, a);
+  return grad ? launch_k(abd_sparse_kernel<R, C, true, ABD_MAXT>, grid, lds, st, a)
+              : launch_k(abd_sparse_kernel<R, C, false, ABD_MAXT>, grid, lds, st, a);
 }
 template <typename R>
 hipError_t launch_sparse(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
@@ -51,7 +55,9 @@ hipError_t launch_sparse(int C, bool grad, dim3 grid, size_t lds, hipStream_t st
 
 template <typename R>
 hipError_t launch_obs(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  return grad ? launch_k(abd_obs_kernel<R, true>, grid, lds, st, a) : launch_k(abd_obs_kernel<R, false>, grid, lds, st, a);
+  if (a.nt > ABD_MAXT)
+    return grad ? launch_k(abd_obs_kernel<R, true, ABD_MAXT_MAX>, grid, lds, st, a) : launch_k(abd_obs_kernel<R, false, ABD_MAXT_MAX>, grid, lds, st, a);
+  return grad ? launch_k(abd_obs_kernel<R, true, ABD_MAXT>, grid, lds, st, a) : launch_k(abd_obs_kernel<R, false, ABD_MAXT>, grid, lds, st, a);
 }
 
 int pick_cpw(const abd_ctx* c, int n) {

@@ -6,6 +6,15 @@
 
 namespace abdi {
 
+// the wave-per-proposal sweep kernel for 4 or 8 words per individual (<= 256 / <= 512 gaps)
+template <typename R, bool DENSE>
+void launch_gibbs_v1(int nt, dim3 grid, size_t lds, hipStream_t st, const GibbsArgs& ga) {
+  if (nt > ABD_MAXT)
+    hipLaunchKernelGGL((abd_gibbs_kernel<R, DENSE, ABD_MAXT_MAX>), grid, dim3(ABD_BLOCK), lds, st, ga);
+  else
+    hipLaunchKernelGGL((abd_gibbs_kernel<R, DENSE, ABD_MAXT>), grid, dim3(ABD_BLOCK), lds, st, ga);
+}
+
 int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,
                          uint32_t stream_offset, hipStream_t st, unsigned long long* counts_dev, unsigned int* work_dev,
                          unsigned long long* stats_dev) {
@@ -36,7 +45,7 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
   if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, 8 * sizeof(unsigned long long), st));
   const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
   const int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
-  if (c->dense && !c->gibbs_v1 && nw2 >= 4) {
+  if (c->dense && !c->gibbs_v1 && nw2 >= 4 && c->nt <= ABD_MAXT) {  // (the lane-per-proposal kernel is built for <= 256 gaps)
     // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
     // per chain
     const size_t lds2 = abd_g2_lds(c->G, rbytes, nw2);
@@ -52,18 +61,18 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
     }
   } else {
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
-    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_GIBBS_WAVE_LDS;
+    const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * abd_gibbs_wave_lds(c->G);
     dim3 grid(blocks, m);
     if (c->dense) {
       if (c->storage == ABD_STORE_F32)
-        hipLaunchKernelGGL((abd_gibbs_kernel<float, true>), grid, dim3(ABD_BLOCK), lds, st, ga);
+        launch_gibbs_v1<float, true>(c->nt, grid, lds, st, ga);
       else
-        hipLaunchKernelGGL((abd_gibbs_kernel<double, true>), grid, dim3(ABD_BLOCK), lds, st, ga);
+        launch_gibbs_v1<double, true>(c->nt, grid, lds, st, ga);
     } else {
       if (c->storage == ABD_STORE_F32)
-        hipLaunchKernelGGL((abd_gibbs_kernel<float, false>), grid, dim3(ABD_BLOCK), lds, st, ga);
+        launch_gibbs_v1<float, false>(c->nt, grid, lds, st, ga);
       else
-        hipLaunchKernelGGL((abd_gibbs_kernel<double, false>), grid, dim3(ABD_BLOCK), lds, st, ga);
+        launch_gibbs_v1<double, false>(c->nt, grid, lds, st, ga);
     }
   }
   HIP_TRY(hipGetLastError());

@@ -37,20 +37,20 @@
 // delta + bound < log u the outcome is settled.  A new infection moves the titers of its own round by a
 // whole boost and is usually rejected there: ~1 round per proposal instead of ~3 at G = 200.  The test is
 // exact (it never changes a decision), with a relative margin of 1e-9 against rounding in the bound.
-template <typename R, bool PROPOSAL>
-__device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& p, int lane, const uint64_t I[ABD_MAXT],
-                                             const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
+template <typename R, bool PROPOSAL, int MT>
+__device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& p, int lane, const uint64_t I[MT],
+                                             const uint64_t V[MT], const double2_t* tab_n, const double2_t* tab_s,
                                              double pwn, double pws, double is2_n, double is2_s,
-                                             const YX<R> (&dn)[ABD_MAXT], const YX<R> (&ds)[ABD_MAXT], int r0,
-                                             double& cvn, double& cvs, double (&out)[ABD_MAXT],
-                                             const double (&cur)[ABD_MAXT], double suf, double logu, double& delta, bool& dead) {
+                                             const YX<R> (&dn)[MT], const YX<R> (&ds)[MT], int r0,
+                                             double& cvn, double& cvs, double (&out)[MT],
+                                             const double (&cur)[MT], double suf, double logu, double& delta, bool& dead) {
   // cvn / cvs: lane t holds the response carried INTO round t (lane 0: 0).  Kept as one vector register each
   // instead of 2 x 5 wave-uniform doubles: the masks already fill the scalar register file.
   double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;  // unused gradient outputs
   bool ci = false, civ = false;                   // any exposure in earlier rounds
   const uint64_t le = (2ull << lane) - 1ull;      // bits at or before this lane (lane 63: all ones)
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if (t < a.nt) {
       if (t >= r0 && !dead) {
         double un = pwn * readlane_f64(cvn, t), us = pws * readlane_f64(cvs, t);
@@ -78,13 +78,13 @@ __device__ __forceinline__ void dense_rounds(const EvalArgs& a, const ChainPar& 
         obs_term<false>(an, (double)dn[t].x, (double)dn[t].y, p.b_n, p.d_n, guard, q2n, d0, d1, d2, d3);
         obs_term<false>(as, (double)ds[t].x, (double)ds[t].y, p.b_s, p.d_s, guard, q2s, d0, d1, d2, d3);
         out[t] = fma(-0.5 * is2_s, q2s, -0.5 * is2_n * q2n);
-        if (t + 1 < ABD_MAXT) {
+        if (t + 1 < MT) {
           cvn = lane == t + 1 ? readlane_f64(un, 63) : cvn;
           cvs = lane == t + 1 ? readlane_f64(us, 63) : cvs;
         }
         if (PROPOSAL) {
           delta += wave_sum_uniform(out[t] - cur[t]);
-          const double rest = t + 1 < ABD_MAXT ? readlane_f64(suf, t + 1) : 0.0;
+          const double rest = t + 1 < MT ? readlane_f64(suf, t + 1) : 0.0;
           if (delta + rest < logu - 1e-9 * (fabs(delta) + rest + 1.0)) dead = true;
         }
       }
@@ -140,14 +140,14 @@ __device__ __forceinline__ ObsLane<R> load_obs_lane(const EvalArgs& a, const Cha
   return o;
 }
 
-template <typename R>
-__device__ __forceinline__ double obs_lane_term(const EvalArgs& a, const ObsLane<R>& o, const uint64_t I[ABD_MAXT],
-                                                const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s) {
+template <typename R, int MT>
+__device__ __forceinline__ double obs_lane_term(const EvalArgs& a, const ObsLane<R>& o, const uint64_t I[MT],
+                                                const uint64_t V[MT], const double2_t* tab_n, const double2_t* tab_s) {
   const double2_t* tb = o.is_s ? tab_s : tab_n;
   double u = 0.0;
   bool cum = false;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if (t < a.nt) {
       const int rel = o.g - t * 64;  // bits <= rel of word t are exposures at or before the observation's gap
       const uint64_t le = rel >= 63 ? ~0ull : (rel < 0 ? 0ull : ((2ull << rel) - 1ull));
@@ -173,21 +173,21 @@ __device__ __forceinline__ double obs_lane_term(const EvalArgs& a, const ObsLane
   return o.nh_is2 * q2;
 }
 
-template <typename R>
-__device__ __forceinline__ double sparse_terms(const EvalArgs& a, const ChainPar& p, int j, int lane, const uint64_t I[ABD_MAXT],
-                                               const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
+template <typename R, int MT>
+__device__ __forceinline__ double sparse_terms(const EvalArgs& a, const ChainPar& p, int j, int lane, const uint64_t I[MT],
+                                               const uint64_t V[MT], const double2_t* tab_n, const double2_t* tab_s,
                                                double is2_n, double is2_s, const ObsLane<R>& first, int n_obs) {
-  double acc = obs_lane_term<R>(a, first, I, V, tab_n, tab_s);
+  double acc = obs_lane_term<R, MT>(a, first, I, V, tab_n, tab_s);
   for (int base = 64; base < n_obs; base += 64) {  // individuals with more than 64 observations: the rest from memory
     const ObsLane<R> o = load_obs_lane<R>(a, p, j, base + lane, is2_n, is2_s);
-    acc += obs_lane_term<R>(a, o, I, V, tab_n, tab_s);
+    acc += obs_lane_term<R, MT>(a, o, I, V, tab_n, tab_s);
   }
   return acc;
 }
 
-template <typename R, bool DENSE>
+template <typename R, bool DENSE, int MT>
 __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga) {
-  // LDS: [2][G+1] power tables of the block's chain, [G+1] ones, then ABD_GIBBS_WAVE_LDS bytes per wave
+  // LDS: [2][G+1] power tables of the block's chain, [G+1] ones, then abd_gibbs_wave_lds(G) bytes per wave
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
   const int G = a.G, N = a.N, nt = a.nt;
@@ -196,11 +196,12 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   double2_t* tab_ones = tabs + 2 * tstride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* wbase = reinterpret_cast<unsigned char*>(tab_ones + tstride) + wave * ABD_GIBBS_WAVE_LDS;
-  uint32_t* keyv = reinterpret_cast<uint32_t*>(wbase);           // [260] sort key by dim
-  uint16_t* order = reinterpret_cast<uint16_t*>(wbase + 1040);   // [260] dim by rank
-  unsigned char* transit = wbase + 1040 + 520;                   // [260] 1 = propose, by dim
-  double* logu = reinterpret_cast<double*>(wbase + 1040 + 520 + 264);  // [260] log of the acceptance uniform, by dim
+  const size_t nd = (size_t)G + 1;
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(tab_ones + tstride) + (size_t)wave * abd_gibbs_wave_lds(G);
+  uint32_t* keyv = reinterpret_cast<uint32_t*>(wbase);                                    // [G+1] sort key by dim
+  uint16_t* order = reinterpret_cast<uint16_t*>(wbase + abd_gibbs_pad16(4 * nd));         // [G+1] dim by rank
+  unsigned char* transit = wbase + abd_gibbs_pad16(4 * nd) + abd_gibbs_pad16(2 * nd);     // [G+1] 1 = propose, by dim
+  double* logu = reinterpret_cast<double*>(transit + abd_gibbs_pad16(nd));                // [G+1] log of the acceptance uniform, by dim
 
   const int c = blockIdx.y;  // one chain per block row
   const ChainPar& p = a.ch[c];
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
     // ---- this individual's discrete state and data ----
-    uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
-    YX<R> dn[ABD_MAXT], ds[ABD_MAXT];
+    uint64_t V[MT], P[MT], Rw[MT], I[MT];
+    YX<R> dn[MT], ds[MT];
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       V[t] = P[t] = Rw[t] = 0;
       dn[t].x = dn[t].y = ds[t].x = ds[t].y = 0;
       if (t < nt) {
@@ -241,10 +242,10 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       }
     }
     bool wj = __builtin_amdgcn_readfirstlane((int)waner[j]) != 0;
-    constrain_masks(Rw, P, a, I);
+    constrain_masks<MT>(Rw, P, a, I);
     int pc0 = wj ? (1 << 16) : 0;  // sum(i_raw) and ab_s_waner of this individual before the sweep
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) pc0 += __builtin_popcountll(Rw[t]);
+    for (int t = 0; t < MT; ++t) pc0 += __builtin_popcountll(Rw[t]);
 
     // ---- random order and transit flags of this individual's dims ----
     for (int d = lane; d < n_dims; d += 64) {
@@ -272,15 +273,15 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
 
     // this lane's terms at the current state (dense: by round of 64 gaps, with the responses carried into
     // each round; sparse: one sum in cur[0])
-    double cur[ABD_MAXT], cur_cn = 0.0, cur_cs = 0.0;
+    double cur[MT], cur_cn = 0.0, cur_cs = 0.0;
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) cur[t] = 0.0;
+    for (int t = 0; t < MT; ++t) cur[t] = 0.0;
     double suf = 0.0;  // lane t: -(sum of the current terms of rounds >= t) >= 0, the most those rounds can give back
     auto refresh_bounds = [&]() {
       double accb = 0.0;
       suf = 0.0;
 #pragma unroll
-      for (int t = ABD_MAXT - 1; t >= 0; --t) {
+      for (int t = MT - 1; t >= 0; --t) {
         if (t < nt) accb -= wave_sum_uniform(cur[t]);
         suf = lane == t ? accb : suf;
       }
@@ -288,11 +289,11 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     if (DENSE) {
       double unused_delta = 0.0;
       bool unused_dead = false;
-      dense_rounds<R, false>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws : 1.0, is2_n, is2_s, dn, ds,
+      dense_rounds<R, false, MT>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws : 1.0, is2_n, is2_s, dn, ds,
                              0, cur_cn, cur_cs, cur, cur, 0.0, 0.0, unused_delta, unused_dead);
       refresh_bounds();
     } else {
-      cur[0] = sparse_terms<R>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
+      cur[0] = sparse_terms<R, MT>(a, p, j, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
     }
 
     // ---- the sweep ----
@@ -301,14 +302,14 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
       if (!__builtin_amdgcn_readfirstlane((int)transit[d])) continue;  // same value proposed: nothing to do
       ++n_prop;
       double delta;
-      uint64_t In[ABD_MAXT];
+      uint64_t In[MT];
       bool wn = wj;
       const uint64_t bit = d < G ? 1ull << (d & 63) : 0ull;  // the proposed flip of i_raw, in word d >> 6
       if (d < G) {
-        uint64_t Rn[ABD_MAXT];
+        uint64_t Rn[MT];
         bool was_one = false;
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) {
+        for (int t = 0; t < MT; ++t) {
           Rn[t] = Rw[t];
           if (t == (d >> 6)) {
             was_one = (Rw[t] & bit) != 0;
@@ -316,36 +317,36 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
           }
         }
         delta = was_one ? -theta0 : theta0;  // Bernoulli(i_raw | p) on the RAW matrix (abd.py:427)
-        constrain_masks(Rn, P, a, In);
+        constrain_masks<MT>(Rn, P, a, In);
       } else {
         wn = !wj;
         delta = wn ? theta7 : -theta7;  // Bernoulli(ab_s_waner | p_waner)   (abd.py:373)
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) In[t] = I[t];
+        for (int t = 0; t < MT; ++t) In[t] = I[t];
       }
       // first round of 64 gaps whose constrained infections differ (a waning flip touches every round)
-      int r0 = wn == wj ? ABD_MAXT : 0;
+      int r0 = wn == wj ? MT : 0;
 #pragma unroll
-      for (int t = ABD_MAXT - 1; t >= 0; --t)
+      for (int t = MT - 1; t >= 0; --t)
         if (In[t] != I[t]) r0 = min(r0, t);
-      double nxt[ABD_MAXT], nxt_cn = cur_cn, nxt_cs = cur_cs;
+      double nxt[MT], nxt_cn = cur_cn, nxt_cs = cur_cs;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) nxt[t] = cur[t];
+      for (int t = 0; t < MT; ++t) nxt[t] = cur[t];
       const double log_u = readfirstlane_f64(logu[d]);
       bool dead = false;  // dense: settled as a rejection before all rounds were evaluated
-      if (r0 < ABD_MAXT) {  // something changed: re-evaluate this individual from there on
+      if (r0 < MT) {  // something changed: re-evaluate this individual from there on
         if (DENSE) {
-          dense_rounds<R, true>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn,
+          dense_rounds<R, true, MT>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws : 1.0, is2_n, is2_s, dn,
                                 ds, r0, nxt_cn, nxt_cs, nxt, cur, suf, log_u, delta, dead);
         } else {
-          nxt[0] = sparse_terms<R>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
+          nxt[0] = sparse_terms<R, MT>(a, p, j, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, is2_n, is2_s, first, n_obs);
           delta += wave_sum_uniform(nxt[0] - cur[0]);
         }
       }
       // metrop_select: keep the flip if delta > 0 or delta > log(u)
       if (!dead && (delta > 0.0 || delta > log_u)) {
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) {
+        for (int t = 0; t < MT; ++t) {
           if (t == (d >> 6)) Rw[t] ^= bit;
           I[t] = In[t];
           cur[t] = nxt[t];
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     // constrained words the evaluation kernels read, the changes of sum(i_raw) and sum(ab_s_waner)) ----
     if (lane == 0) {
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t)
+      for (int t = 0; t < MT; ++t)
         if (t < nt) {
           rw[(int64_t)t * N + j] = Rw[t];
           iw[(int64_t)t * N + j] = I[t];
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     }
     int pc1 = wj ? (1 << 16) : 0;
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) pc1 += __builtin_popcountll(Rw[t]);
+    for (int t = 0; t < MT; ++t) pc1 += __builtin_popcountll(Rw[t]);
     d_n1 += (pc1 & 0xFFFF) - (pc0 & 0xFFFF);
     d_m1 += (pc1 >> 16) - (pc0 >> 16);
   }

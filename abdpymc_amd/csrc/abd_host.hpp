@@ -26,7 +26,7 @@
 #include "abd_terms.hpp"
 
 static_assert(ABD_MAX_BATCH == ABD_MAX_BATCH_K, "header / kernel batch size mismatch");
-static_assert(ABD_MAX_GAPS == 64 * ABD_MAXT, "header / kernel gap limit mismatch");
+static_assert(ABD_MAX_GAPS == 64 * ABD_MAXT_MAX, "header / kernel gap limit mismatch");
 static_assert(ABD_N_THETA == ABD_NT, "header / kernel value-variable count mismatch");
 
 namespace abdi {
@@ -74,7 +74,7 @@ struct AntigenDev {
   int64_t K = 0;
   void* y = nullptr;       // sparse: R[K], sorted by (ind, gap)
   void* x = nullptr;       // sparse: R[K]
-  uint8_t* g = nullptr;    // sparse: gap per obs
+  uint16_t* g = nullptr;   // sparse: gap per obs
   int32_t* ptr = nullptr;  // sparse: (N+1)
   int32_t* j = nullptr;    // sparse: individual per obs
   void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
@@ -118,7 +118,7 @@ struct abd_ctx {
   int blocks_max = 0;     // rows per chain in `partials`
   int cpw_forced = 0;
   int dense_blocks = 0;   // dense kernel grid.x
-  uint64_t chunk_mask[3][ABD_MAXT] = {};
+  uint64_t chunk_mask[3][ABD_MAXT_MAX] = {};
   AntigenDev s, n;
   uint64_t* vw = nullptr;  // [nt][N]
   uint64_t* pw = nullptr;  // [nt][N]

@@ -43,7 +43,7 @@ __host__ __device__ inline size_t abd_obs_lds_head(int G) {
   return (size_t)2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double) + 16;
 }
 
-template <typename R, bool GRAD>
+template <typename R, bool GRAD, int MT>
 __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int G = a.G, N = a.N, nt = a.nt, tstride = G + 1;
@@ -66,20 +66,13 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
       const int j = a.j_n[k];
       const int g = a.g_n[k];
       const double y = ld<R>(a.y_n, k), x = ld<R>(a.x_n, k);
-      uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+      uint64_t I[MT];  // the individual's constrained infections (kept with the chain slot)
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
-        P[t] = Rw[t] = 0;
-        if (t < nt) {
-          Rw[t] = p.rw[(int64_t)t * N + j];
-          if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
-        }
-      }
-      constrain_masks(Rw, P, a, I);
+      for (int t = 0; t < MT; ++t) I[t] = t < nt ? p.iw[(int64_t)t * N + j] : 0ull;
       double un = 0.0, dn = 0.0;
       bool cum = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t)
+      for (int t = 0; t < MT; ++t)
         if (t < nt) {
           cum |= any_bits(I[t], t, g);
           add_bits(I[t], t, g, tab, un, dn);
@@ -103,23 +96,21 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
       const int j = a.j_s[k];
       const int g = a.g_s[k];
       const double y = ld<R>(a.y_s, k), x = ld<R>(a.x_s, k);
-      uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT], V[ABD_MAXT];
+      uint64_t I[MT], V[MT];
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
-        P[t] = Rw[t] = V[t] = 0;
+      for (int t = 0; t < MT; ++t) {
+        I[t] = V[t] = 0;
         if (t < nt) {
-          Rw[t] = p.rw[(int64_t)t * N + j];
+          I[t] = p.iw[(int64_t)t * N + j];
           V[t] = a.vw[(int64_t)t * N + j];
-          if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
         }
       }
-      constrain_masks(Rw, P, a, I);
       const bool wj = p.waner[j] != 0;
       const double2_t* ts = wj ? tab : tab_ones;
       double us = 0.0, ds = 0.0;
       bool cum = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t)
+      for (int t = 0; t < MT; ++t)
         if (t < nt) {
           cum |= any_bits(I[t] | V[t], t, g);
           add_bits(I[t], t, g, ts, us, ds);  // an infection and a dose in the same gap both count (Q5)
@@ -134,15 +125,12 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
       }
     }
   } else {
-    // ---- Bernoulli counts on the RAW indicators (Q2) and on waner
+    // ---- Bernoulli counts on the RAW indicators (Q2) and on waner: the slot's counters (abd_constrain_kernel keeps them)
     const int b0 = b - a.ob_n - a.ob_s;
-    int n1 = 0, m1 = 0;
-    for (int j = b0 * ABD_BLOCK + tid; j < N; j += a.ob_c * ABD_BLOCK) {
-      for (int t = 0; t < nt; ++t) n1 += __builtin_popcountll(p.rw[(int64_t)t * N + j]);
-      m1 += p.waner[j] != 0;
+    if (b0 == 0 && tid == 0) {
+      acc[0] = (double)p.cnt[0];
+      acc[1] = (double)p.cnt[1];
     }
-    acc[0] = (double)n1;
-    acc[1] = (double)m1;
   }
 
 #pragma unroll

@@ -35,20 +35,21 @@ __global__ __launch_bounds__(256) void abd_pack_bits_kernel(const int8_t* __rest
 struct ConstrainArgs {
   const uint64_t* pw;  // [nt][N] packed pcrpos, nullptr = ignore_pcrpos
   int32_t N, nt, n_chunks, pad_;
-  uint64_t chunk_mask[3][ABD_MAXT];
+  uint64_t chunk_mask[3][ABD_MAXT_MAX];
 };
 
 // Refresh a chain slot's cached state from its raw discrete state: iw = constrain(rw, pcrpos) (abd.py:640-667) for every
 // individual, cnt[0] += sum(i_raw), cnt[1] += sum(ab_s_waner) (the caller zeroes cnt; integer adds: order-free).
+template <int MT>
 __global__ __launch_bounds__(256) void abd_constrain_kernel(const ConstrainArgs a, const uint64_t* __restrict__ rw,
                                                             const int8_t* __restrict__ waner, uint64_t* __restrict__ iw,
                                                             unsigned long long* cnt) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   int n1 = 0, m1 = 0;
   if (j < a.N) {
-    uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+    uint64_t P[MT], Rw[MT], I[MT];
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       P[t] = Rw[t] = 0;
       if (t < a.nt) {
         Rw[t] = rw[(int64_t)t * a.N + j];
@@ -56,9 +57,9 @@ __global__ __launch_bounds__(256) void abd_constrain_kernel(const ConstrainArgs 
         n1 += __builtin_popcountll(Rw[t]);
       }
     }
-    constrain_masks(Rw, P, a, I);
+    constrain_masks<MT>(Rw, P, a, I);
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t)
+    for (int t = 0; t < MT; ++t)
       if (t < a.nt) iw[(int64_t)t * a.N + j] = I[t];
     m1 = waner[j] != 0;
   }
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void abd_constrain_kernel(const ConstrainArgs 
 }
 
 // One proposed flip of the resident state (abd_flip_discrete): the bit, its individual's constrained words, the counters
+template <int MT>
 __global__ void abd_flip_kernel(const ConstrainArgs a, uint64_t* rw, int8_t* waner, uint64_t* iw, unsigned long long* cnt, int G,
                                 int64_t flat) {
   const int N = a.N;
@@ -84,18 +86,18 @@ __global__ void abd_flip_kernel(const ConstrainArgs a, uint64_t* rw, int8_t* wan
     const uint64_t w = rw[(g >> 6) * N + j] ^ bit;
     rw[(g >> 6) * N + j] = w;
     cnt[0] += (w & bit) ? 1ull : ~0ull;  // +1 / -1
-    uint64_t P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+    uint64_t P[MT], Rw[MT], I[MT];
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
+    for (int t = 0; t < MT; ++t) {
       P[t] = Rw[t] = 0;
       if (t < a.nt) {
         Rw[t] = rw[(int64_t)t * N + j];
         if (a.pw) P[t] = a.pw[(int64_t)t * N + j];
       }
     }
-    constrain_masks(Rw, P, a, I);
+    constrain_masks<MT>(Rw, P, a, I);
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t)
+    for (int t = 0; t < MT; ++t)
       if (t < a.nt) iw[(int64_t)t * N + j] = I[t];
   } else {
     const int8_t w = waner[flat - gn] ^ 1;
@@ -106,6 +108,7 @@ __global__ void abd_flip_kernel(const ConstrainArgs a, uint64_t* rw, int8_t* wan
 
 // Deterministics "i", "ab_n_mu", "ab_s_mu" for one chain, written (G, N) gap-major as PyMC records them;
 // with `sums` ([3][G*N]: i, ab_n_mu, ab_s_mu) they are also added to running sums (posterior means on device).
+template <int MT>
 __global__ __launch_bounds__(ABD_BLOCK) void abd_deterministics_kernel(const EvalArgs a, int8_t* __restrict__ out_i,
                                                                        double* __restrict__ out_mun,
                                                                        double* __restrict__ out_mus,
@@ -123,23 +126,21 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_deterministics_kernel(const Eva
   __syncthreads();
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
-    uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT];
+    uint64_t V[MT], I[MT];  // vaccinations; the chain's constrained infections (kept with the slot)
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
-      V[t] = P[t] = Rw[t] = 0;
+    for (int t = 0; t < MT; ++t) {
+      V[t] = I[t] = 0;
       if (t < nt) {
         V[t] = uniform_word(a.vw, (int64_t)t * N + j);
-        if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
-        Rw[t] = uniform_word(p.rw, (int64_t)t * N + j);
+        I[t] = uniform_word(p.iw, (int64_t)t * N + j);
       }
     }
-    constrain_masks(Rw, P, a, I);
     const bool wj = __builtin_amdgcn_readfirstlane((int)p.waner[j]) != 0;
     const double2_t* ts = wj ? tabs + tstride : tab_ones;
     for (int t = 0; t < nt; ++t) {
       const int g = t * 64 + lane;
       if (g < G) {
-        const Resp rs = responses(g, t + 1, I, V, tabs, ts);
+        const Resp rs = responses<MT>(g, t + 1, I, V, tabs, ts);
         const int64_t o = (int64_t)g * N + j;
         const int bit = (int)((I[t] >> lane) & 1ull);
         const double mun = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;

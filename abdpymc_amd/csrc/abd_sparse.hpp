@@ -5,7 +5,7 @@
 
 #include "abd_device.hpp"
 
-template <typename R, int CPW, bool GRAD>
+template <typename R, int CPW, bool GRAD, int MT>
 __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS: [CPW][2][G+1] power tables + [G+1] "ones" table + block reduction
@@ -35,46 +35,41 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
   for (int c = 0; c < CPW; ++c)
 #pragma unroll
     for (int k = 0; k < ABD_NACC; ++k) acc[c][k] = 0.0;
-  int n1[CPW], m1[CPW];
+  // sum(i_raw), sum(ab_s_waner): the slot's counters, carried into the sums by the chain's first wave
+  double n1[CPW], m1[CPW];
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) n1[c] = m1[c] = 0;
+  for (int c = 0; c < CPW; ++c) {
+    const bool first = blockIdx.x == 0 && wave == 0;
+    n1[c] = first ? (double)a.ch[cbase + c].cnt[0] : 0.0;
+    m1[c] = first ? (double)a.ch[cbase + c].cnt[1] : 0.0;
+  }
 
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
-    uint64_t V[ABD_MAXT], P[ABD_MAXT], I[CPW][ABD_MAXT];
-    {
-      uint64_t Rw[CPW][ABD_MAXT];
+    // the individual's vaccination words and each chain's CONSTRAINED infection words (kept with the chain slot:
+    // abd_small.hpp: abd_constrain_kernel), wave-uniform
+    uint64_t V[MT], I[CPW][MT];
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
-        V[t] = 0;
-        P[t] = 0;
+    for (int t = 0; t < MT; ++t) {
+      V[t] = 0;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) Rw[c][t] = 0;
-        if (t < nt) {
-          V[t] = uniform_word(a.vw, (int64_t)t * N + j);
-          if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
+      for (int c = 0; c < CPW; ++c) I[c][t] = 0;
+      if (t < nt) {
+        V[t] = uniform_word(a.vw, (int64_t)t * N + j);
 #pragma unroll
-          for (int c = 0; c < CPW; ++c) Rw[c][t] = uniform_word(a.ch[cbase + c].rw, (int64_t)t * N + j);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        constrain_masks(Rw[c], P, a, I[c]);
-#pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) n1[c] += __builtin_popcountll(Rw[c][t]);
+        for (int c = 0; c < CPW; ++c) I[c][t] = uniform_word(a.ch[cbase + c].iw, (int64_t)t * N + j);
       }
     }
     int wj[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       wj[c] = __builtin_amdgcn_readfirstlane((int)a.ch[cbase + c].waner[j]) != 0;
-      m1[c] += wj[c];
     }
 
 #pragma unroll
     for (int ag = 0; ag < 2; ++ag) {
       const int32_t* ptr = ag == 0 ? a.ptr_n : a.ptr_s;
-      const uint8_t* gi = ag == 0 ? a.g_n : a.g_s;
+      const uint16_t* gi = ag == 0 ? a.g_n : a.g_s;
       const void* yy = ag == 0 ? a.y_n : a.y_s;
       const void* xx = ag == 0 ? a.x_n : a.x_s;
       const int k0 = ptr[j], k1 = ptr[j + 1];
@@ -90,7 +85,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
           const ChainPar& p = a.ch[cbase + c];
           const double2_t* tn = tabs + (c * 2 + 0) * tstride;
           const double2_t* ts = wj[c] ? tabs + (c * 2 + 1) * tstride : tab_ones;
-          const Resp rs = responses(g, nt, I[c], V, tn, ts);
+          const Resp rs = responses<MT>(g, nt, I[c], V, tn, ts);
           double h = 0.0;
           if (ag == 0) {
             const double an = p.init_n + (rs.cum_i ? p.perm_n : 0.0) + p.temp_n * rs.un;
@@ -122,8 +117,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_sparse_kernel(const EvalArgs a)
       if (lane == 0) red[(wave * CPW + c) * ABD_NOUT + k] = v;
     }
     if (lane == 0) {
-      red[(wave * CPW + c) * ABD_NOUT + ABD_NACC] = (double)n1[c];
-      red[(wave * CPW + c) * ABD_NOUT + ABD_NACC + 1] = (double)m1[c];
+      red[(wave * CPW + c) * ABD_NOUT + ABD_NACC] = n1[c];
+      red[(wave * CPW + c) * ABD_NOUT + ABD_NACC + 1] = m1[c];
       red[(wave * CPW + c) * ABD_NOUT + ABD_NACC + 2] = 0.0;
     }
   }

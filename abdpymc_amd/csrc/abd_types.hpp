@@ -10,7 +10,9 @@
 #endif
 #include <stdint.h>
 
-#define ABD_MAXT 4          // 64-gap words per individual (G <= 256)
+#define ABD_MAXT 4          // 64-gap words per individual the register-resident kernels are built for by default (G <= 256) ...
+#define ABD_MAXT_MAX 8      // ... and at most (G <= 512): the kernels that hold an individual's words in registers are
+                            // templates over the word count (4 or 8); the dense evaluation kernel reads words on demand
 #define ABD_NACC 13         // floating sums per chain (see enum below)
 #define ABD_NOUT 16         // ABD_NACC + n1 + m1, padded
 #define ABD_MAX_BATCH_K 16  // chains per launch
@@ -93,8 +95,8 @@ struct EvalArgs {
   const void* x_n;
   const void* y_s;
   const void* x_s;
-  const uint8_t* g_n;
-  const uint8_t* g_s;
+  const uint16_t* g_n;  // gap of each observation
+  const uint16_t* g_s;
   const int32_t* ptr_n;
   const int32_t* ptr_s;
   const int32_t* j_n;  // individual of each observation (observation-lane kernel)
@@ -130,7 +132,7 @@ struct EvalArgs {
   double fin_tag;
   int32_t G, N, nt, n_chunks;
   int32_t n_chains, n_lg;     // n_lg: 64-individual lane groups (dense kernel)
-  uint64_t chunk_mask[3][ABD_MAXT];
+  uint64_t chunk_mask[3][ABD_MAXT_MAX];
   ChainPar ch[ABD_MAX_BATCH_K];
   TrainArgs train;  // dense kernel, one chain per launch (abd_sampler.hip)
 };
@@ -177,7 +179,12 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 }
 
 #define ABD_TRANSIT_P_U32 3435973836u  // floor(0.8 * 2^32): propose iff word 1 < this   (transit_p = 0.8)
-#define ABD_GIBBS_WAVE_LDS 3904        // per wave: keys u32[260] + order u16[260] + transit u8[260] (padded to 264) + log u f64[260]
+// per-wave LDS of abd_gibbs_kernel: sort keys u32[G+1] + order u16[G+1] + transit u8[G+1] + log u f64[G+1], each padded to 16 bytes
+__host__ __device__ inline size_t abd_gibbs_pad16(size_t b) { return (b + 15) / 16 * 16; }
+__host__ __device__ inline size_t abd_gibbs_wave_lds(int G) {
+  const size_t n = (size_t)G + 1;
+  return abd_gibbs_pad16(4 * n) + abd_gibbs_pad16(2 * n) + abd_gibbs_pad16(n) + abd_gibbs_pad16(8 * n);
+}
 
 struct GibbsArgs {
   EvalArgs e;  // panels, packed words, chain parameters (ch[k].rw / waner are updated IN PLACE)

@@ -31,10 +31,12 @@ extern "C" {
 #endif
 
 #define ABD_N_THETA 17
-/* Limit of this library that the reference does not have: abdpymc takes any n_gaps (abd.py:101, 224-239); here an
- * individual's gap axis is held as 4 x 64-bit packed words in registers, so n_gaps <= 256 (abd_create refuses more with
- * ABD_ERR_ARG).  The reference's cohorts have 26 / 31 monthly gaps, BASELINE's synthetic ones 60 / 200. */
-#define ABD_MAX_GAPS 256
+/* Limit of this library that the reference does not have: abdpymc takes any n_gaps (abd.py:101, 224-239); here the
+ * kernels that hold an individual's gap axis in registers (observation lists, the sweep, the Deterministics) are built
+ * for 4 and for 8 packed 64-bit words, so n_gaps <= 512 (abd_create refuses more with ABD_ERR_ARG; the dense evaluation
+ * kernel reads words on demand and has no such limit of its own).  The reference's cohorts have 26 / 31 monthly gaps,
+ * BASELINE's synthetic ones 60 / 200.  Beyond 256 gaps dense cohorts sweep with the wave-per-proposal kernel. */
+#define ABD_MAX_GAPS 512
 #define ABD_MAX_BATCH 16  /* chains per kernel launch (larger batches are split) */
 
 typedef enum {

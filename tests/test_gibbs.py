@@ -132,7 +132,8 @@ def _ctx(coh, splits=None, ignore=False, n_chains=1, storage="f64"):
 
 
 @gpu
-@pytest.mark.parametrize("G,N,splits", [(20, 23, None), (70, 130, (30,)), (200, 64, (66, 133)), (256, 9, None), (5, 300, (2,))])
+@pytest.mark.parametrize("G,N,splits", [(20, 23, None), (70, 130, (30,)), (200, 64, (66, 133)), (256, 9, None), (5, 300, (2,)),
+                                        (300, 40, (100, 200)), (512, 11, None)])  # beyond 256 gaps: the 8-word wave-per-proposal kernel
 def test_gpu_sweep_matches_cpu_restatement_dense(G, N, splits):
     coh = oracle_cohort_from_synth(synthetic.make_cohort(N, G, seed=G + N))
     co = c_oracle.COracle(coh, splits)
@@ -160,7 +161,8 @@ def test_gpu_sweep_matches_cpu_restatement_dense(G, N, splits):
 
 @gpu
 @pytest.mark.parametrize("ignore", [False, True])
-@pytest.mark.parametrize("N,G,ks,kn,splits", [(41, 26, 900, 700, (10,)), (12, 200, 2500, 2100, (66, 133)), (30, 70, 40, 0, None)])
+@pytest.mark.parametrize("N,G,ks,kn,splits", [(41, 26, 900, 700, (10,)), (12, 200, 2500, 2100, (66, 133)), (30, 70, 40, 0, None),
+                                              (9, 300, 900, 800, (150,)), (7, 512, 600, 700, None)])
 def test_gpu_sweep_matches_cpu_restatement_sparse(ignore, N, G, ks, kn, splits):
     coh = random_sparse_cohort(N, G, ks, kn, seed=5)
     co = c_oracle.COracle(coh, splits, ignore)

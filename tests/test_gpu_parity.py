@@ -48,7 +48,7 @@ def assert_close(lp, g, lp_ref, g_ref, rtol=RTOL):
     assert err.max() <= rtol, (err, g, g_ref)
 
 
-@pytest.mark.parametrize("G,N", [(20, 23), (60, 100), (64, 65), (65, 7), (200, 50), (256, 9), (2, 5)])
+@pytest.mark.parametrize("G,N", [(20, 23), (60, 100), (64, 65), (65, 7), (200, 50), (256, 9), (2, 5), (257, 70), (300, 130), (512, 67)])
 @pytest.mark.parametrize("splits", [None, "one", "two"])
 def test_dense_parity(G, N, splits):
     coh = oracle_cohort_from_synth(synthetic.make_cohort(N, G, seed=G * 1000 + N))
@@ -398,4 +398,31 @@ def test_many_evaluations_in_one_call():
         np.testing.assert_array_equal(g[k], g1)
     with pytest.raises(ValueError):
         ctx.logp_dlogp_many([0, 1], th[:, :1])
+    ctx.close()
+
+
+@pytest.mark.parametrize("lanes", ["1", "0"])
+@pytest.mark.parametrize("G,splits", [(300, (100, 201)), (512, (256,)), (449, None)])
+def test_more_than_256_gaps_observation_lists_and_deterministics(G, splits, lanes, monkeypatch):
+    """The reference takes any n_gaps (abd.py:101, 224-239).  Beyond 256 gaps the kernels that hold an individual's gap
+    axis in registers run in their 8-word form: both observation-list kernels, the Deterministics, the flip path."""
+    monkeypatch.setenv("ABD_OBS_LANES", lanes)
+    coh = random_sparse_cohort(29, G, 1500, 1200, seed=G)
+    ctx = _ctx(coh, splits)
+    assert not ctx.is_dense
+    theta, i_raw, w = _state(coh, 3)
+    i_raw[-1, :5] = 1  # the last gap of the axis
+    ctx.set_discrete(0, i_raw, w)
+    lp, g = ctx.logp_dlogp(0, theta)
+    lp_ref, g_ref = O.logp_dlogp(theta, i_raw, w, coh, splits)
+    assert_close(lp, g, lp_ref, g_ref)
+    i_dev, mun, mus = ctx.deterministics(0, theta)
+    i_ref = O.constrain_infections(i_raw, np.asarray(coh.pcrpos).T, splits)
+    np.testing.assert_array_equal(i_dev, i_ref)
+    # one flipped bit in the upper words: the slot's cached constrained words and counters follow
+    flat = (G - 2) * coh.n_inds + 7
+    ctx.flip_discrete(0, flat)
+    i_raw.ravel()[flat] ^= 1
+    lp2, g2 = ctx.logp_dlogp(0, theta)
+    assert_close(lp2, g2, *O.logp_dlogp(theta, i_raw, w, coh, splits))
     ctx.close()

@@ -52,13 +52,19 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
     HIP_TRY(hipMemsetAsync(work_dev, 0, (size_t)m * sizeof(unsigned int), st));
     const int bx = std::max(1, std::min(c->n_cu / m, (c->N + nw2 - 1) / nw2));
     dim3 grid2(bx, m);
-    if (c->storage == ABD_STORE_F32) {
-      if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      hipLaunchKernelGGL((abd_gibbs_dense_kernel<float>), grid2, dim3(64 * nw2), lds2, st, ga);
-    } else {
-      if (lds2 > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(abd_gibbs_dense_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      hipLaunchKernelGGL((abd_gibbs_dense_kernel<double>), grid2, dim3(64 * nw2), lds2, st, ga);
-    }
+    auto launch2 = [&](auto kernel) -> hipError_t {
+      if (lds2 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kernel, grid2, dim3(64 * nw2), lds2, st, ga);
+      return hipSuccess;
+    };
+    const bool f32 = c->storage == ABD_STORE_F32;
+    if (stats_dev)  // ABD_GIBBS_STATS=1: the variant with the scheduler's development counters
+      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, true>) : launch2(abd_gibbs_dense_kernel<double, true>));
+    else
+      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, false>) : launch2(abd_gibbs_dense_kernel<double, false>));
   } else {
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
     const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * abd_gibbs_wave_lds(c->G);

@@ -287,7 +287,9 @@ __device__ __forceinline__ void bitonic_sort_256(uint32_t (&k)[4], int lane) {
   BitonicJ<256, 128>::run(k, lane);
 }
 
-template <typename R>
+// STATS: the development counters of ABD_GIBBS_STATS=1 (seven wave-uniform 64-bit counters: 14 scalar registers the product
+// kernel does not have to spare)
+template <typename R, bool STATS>
 __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   uint64_t* rw = const_cast<uint64_t*>(cp.rw);
   int8_t* waner = const_cast<int8_t*>(cp.waner);
   uint64_t* iw = const_cast<uint64_t*>(cp.iw);
-  long long d_n1 = 0, d_m1 = 0;  // changes of sum(i_raw), sum(ab_s_waner) over this wave's individuals
+  int d_n1 = 0, d_m1 = 0;  // changes of sum(i_raw), sum(ab_s_waner) over this wave's individuals
   unsigned long long n_acc = 0, n_prop_total = 0;
   unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
@@ -425,6 +427,8 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       g2_eval_rounds<R>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, un,
                         us, term);
       double carry = 0.0;
+      int ln = lane;  // (opaque: left to itself the compiler hoists the scan's six "lane + off < 64" masks out of the
+      asm volatile("" : "+v"(ln));  // individual loop and keeps them in 12 scalar registers for the whole kernel)
 #pragma unroll
       for (int t = ABD_MAXT - 1; t >= 0; --t) {
         if (t < nt) {
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) {
             const double y = __shfl_down(x, off, 64);
-            x += lane + off < 64 ? y : 0.0;
+            x += ln + off < 64 ? y : 0.0;
           }
           x += carry;
           if (g < G) suf[g] = x;
@@ -458,9 +462,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
 
     bool dirty = false;  // a result has been written since the last commit scan
-    ++st_inds;
+    if (STATS) ++st_inds;
     for (int iter = 0; iter < ABD_G2_ITER_CAP && frontier < n_prop; ++iter) {
-      ++st_iter;
+      if (STATS) ++st_iter;
       // every iteration commits, hands out or advances at least one proposal, and an acceptance -- the only event that
       // moves `next` back -- changes the state for good: the loop ends; the cap only bounds a defect
       const double rho_j = wj ? p.rho_s : 1.0;  // abd.py:374
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       if (next < n_prop && (n_idle >= ga.refill_min || n_idle == 64)) {
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0));
         const bool take = !active && next + rank < n_prop;
-        ++st_refill;
+        if (STATS) ++st_refill;
         dirty = true;  // immediate results (no change / waning flip) may be among them
         if (take) {
           pidx = next + rank;
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       // that is not rejected early is as long as the gaps that are left).  The whole wave finishes one of them per
       // iteration, lanes = the remaining gaps: the bound at the last gap IS delta.
       const uint64_t walking = __builtin_amdgcn_ballot_w64(active);
-      if (ga.stats) {
+      if (STATS) {
         const uint64_t stepped = walking | __builtin_amdgcn_ballot_w64(finished);
         st_steps += stepped != 0;
         st_lane_steps += (unsigned long long)__builtin_popcountll(stepped);
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       const uint64_t old_walkers = __builtin_amdgcn_ballot_w64(active && g - g_first >= ga.tail_age);
       if (next >= n_prop && old_walkers != 0 && __builtin_popcountll(walking) <= ga.tail_lanes) {
         const int L = __builtin_ctzll(old_walkers);
-        ++st_tail;
+        if (STATS) ++st_tail;
         const int g_l = __builtin_amdgcn_readlane(g, L);
         uint64_t In_l[ABD_MAXT], Is[ABD_MAXT], Vs[ABD_MAXT];
 #pragma unroll
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       // ---- 3. commit in the sweep's order ----
       if (!dirty) continue;
       dirty = false;
-      ++st_commit;
+      if (STATS) ++st_commit;
       for (;;) {
         const int pos = frontier + lane;
         const int r = pos < next ? (int)result[pos] : ABD_G2_PENDING;
@@ -688,14 +692,14 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   }
   if (lane == 0 && (d_n1 | d_m1)) {
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(const_cast<long long*>(cp.cnt));
-    atomicAdd(cnt + 0, (unsigned long long)d_n1);  // two's complement: a negative change wraps to the right sum
-    atomicAdd(cnt + 1, (unsigned long long)d_m1);
+    atomicAdd(cnt + 0, (unsigned long long)(long long)d_n1);  // two's complement: a negative change wraps to the right sum
+    atomicAdd(cnt + 1, (unsigned long long)(long long)d_m1);
   }
   if (lane == 0 && (n_acc | n_prop_total)) {
     atomicAdd(ga.counts + 2 * c + 0, n_acc);
     atomicAdd(ga.counts + 2 * c + 1, n_prop_total);
   }
-  if (lane == 0 && ga.stats) {
+  if (STATS && lane == 0 && ga.stats) {
     atomicAdd(ga.stats + 0, st_inds);
     atomicAdd(ga.stats + 1, st_iter);
     atomicAdd(ga.stats + 2, st_refill);

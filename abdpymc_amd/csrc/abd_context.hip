@@ -108,6 +108,14 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.ob_c = c->ob_c;
   a.yx_n = c->n.yx;
   a.yx_s = c->s.yx;
+  a.od_n = c->n.od;
+  a.od_s = c->s.od;
+  a.xc_n = c->n.xc;
+  a.xc_s = c->s.xc;
+  a.dict_n = c->n.dict;
+  a.dict_s = c->s.dict;
+  a.n_dict_n = c->n.n_dict;
+  a.n_dict_s = c->s.n_dict;
   a.vw = c->vw;
   a.pw = c->ignore_pcr ? nullptr : c->pw;
   a.exp2_tab = c->exp2_tab;
@@ -249,6 +257,33 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
       }
     HIP_TRY(hipMalloc(&d.yx, yx.size() * sizeof(YX<R>)));
     HIP_TRY(hipMemcpy(d.yx, yx.data(), yx.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
+    // the split panels of one-chain launches: od alone + one byte per cell coding its log dilution (assays use a handful of
+    // dilutions; lossless: the dictionary holds the doubles as given)
+    std::vector<double> dict;
+    std::vector<uint8_t> code((size_t)G * N);
+    bool fits = true;
+    for (size_t k = 0; k < K && fits; ++k) {
+      const double x = o.log_dilution[k];
+      size_t q = 0;
+      while (q < dict.size() && std::memcmp(&dict[q], &x, sizeof x) != 0) ++q;  // bit-wise: -0.0, NaN payloads stay what they are
+      if (q == dict.size()) {
+        if (dict.size() == ABD_XDICT) fits = false;
+        else dict.push_back(x);
+      }
+      if (fits) code[(size_t)o.idx_gap[k] * N + (size_t)o.idx_ind[k]] = (uint8_t)q;
+    }
+    if (fits) {
+      std::vector<R> od((size_t)G * N);
+      for (size_t cell = 0; cell < od.size(); ++cell) od[cell] = yx[cell].y;
+      d.n_dict = (int)dict.size();
+      HIP_TRY(hipMalloc(&d.od, od.size() * sizeof(R)));
+      HIP_TRY(hipMemcpy(d.od, od.data(), od.size() * sizeof(R), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&d.xc, code.size()));
+      HIP_TRY(hipMemcpy(d.xc, code.data(), code.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&d.dict, ABD_XDICT * sizeof(double)));
+      dict.resize(ABD_XDICT, 0.0);
+      HIP_TRY(hipMemcpy(d.dict, dict.data(), ABD_XDICT * sizeof(double), hipMemcpyHostToDevice));
+    }
     return ABD_OK;
   }
   std::vector<R> y(std::max<size_t>(K, 1)), x(std::max<size_t>(K, 1));
@@ -295,6 +330,9 @@ void free_ctx(abd_ctx* c) {
     if (a->ptr) (void)hipFree(a->ptr);
     if (a->j) (void)hipFree(a->j);
     if (a->yx) (void)hipFree(a->yx);
+    if (a->od) (void)hipFree(a->od);
+    if (a->xc) (void)hipFree(a->xc);
+    if (a->dict) (void)hipFree(a->dict);
   }
   if (c->vw) (void)hipFree(c->vw);
   if (c->pw) (void)hipFree(c->pw);
@@ -472,6 +510,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     free_ctx(c);
     return rc;
   }
+  c->xc_ok = c->dense && c->s.od && c->n.od;
   const size_t cells = (size_t)G * N;
   const size_t words = (size_t)c->nt * N;
   {
@@ -696,6 +735,8 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   const int64_t cells = (int64_t)c->G * c->N;
   // indicator panels are bit-packed in 64-gap words: vacs + pcrpos + one i_raw per chain, plus the waner bytes
   const int64_t bits = (int64_t)c->nt * c->N * 8 * (2 + n_chains) + (int64_t)n_chains * c->N;
+  // one chain per launch reads the split panels (od + a one-byte dilution code per cell and antigen) where they exist
+  if (c->dense && c->xc_ok && (n_chains & 1)) return cells * 2 * (R + 1) + bits;
   if (c->dense) return cells * 4 * R + bits;
   return (c->s.K + c->n.K) * (2 * R + 2) + 2 * (int64_t)(c->N + 1) * 4 + bits;
 }

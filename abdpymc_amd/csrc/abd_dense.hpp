@@ -59,6 +59,79 @@ __device__ __forceinline__ YX<float> load_yx<float>(const __amdgpu_buffer_rsrc_t
   return r;
 }
 
+// ---- where a gap row's {od, log_dilution} comes from ----
+// XC = false: the pair panel, [G][N] of {od, log_dilution} in the storage type: 2 R bytes per cell and antigen.
+// XC = true:  the split panels of a launch that evaluates ONE chain and therefore reads every byte for that chain alone (a
+//             NUTS chain's leapfrogs, abd.py:922; BASELINE config 5): od [G][N] in the storage type + a one-byte code per
+//             cell into the antigen's dictionary of distinct log dilutions (assays use a handful of dilutions; abd_create
+//             builds the code panel when an antigen has <= 256 distinct values) -- R + 1 bytes per cell and antigen, lossless;
+//             the dictionary (<= 2 KB) sits in LDS.  Four independent chains at config 3 are bound by these bytes.
+template <typename R, bool XC>
+struct RowData;
+template <typename R>
+struct RowData<R, false> {
+  YX<R> v;
+};
+template <typename R>
+struct RowData<R, true> {
+  R y;
+  uint32_t code;
+};
+template <bool XC>
+struct RowDesc;  // buffer descriptors of one antigen's panel(s), based at a piece's first row (wave-uniform)
+template <>
+struct RowDesc<false> {
+  __amdgpu_buffer_rsrc_t rs;
+};
+template <>
+struct RowDesc<true> {
+  __amdgpu_buffer_rsrc_t rs_y, rs_c;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void* base, int64_t byte_off) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off, 0, -1, 0x00020000);
+}
+// (built outside divergent code, or every load through a descriptor becomes a waterfall loop)
+template <typename R, bool XC>
+__device__ __forceinline__ RowDesc<XC> row_desc(const EvalArgs& a, int antigen, int lg, int g0) {
+  const int64_t cell0 = (int64_t)g0 * a.N + (int64_t)lg * 64;
+  RowDesc<XC> d;
+  if constexpr (XC) {
+    d.rs_y = rsrc_at(antigen ? a.od_s : a.od_n, cell0 * (int64_t)sizeof(R));
+    d.rs_c = rsrc_at(antigen ? a.xc_s : a.xc_n, cell0);
+  } else {
+    d.rs = rsrc_at(antigen ? a.yx_s : a.yx_n, cell0 * (int64_t)sizeof(YX<R>));
+  }
+  return d;
+}
+// row `row` (relative to the descriptor's base) for this lane: scalar row offset + a constant per-lane offset
+template <typename R, bool XC>
+__device__ __forceinline__ RowData<R, XC> row_load(const RowDesc<XC>& d, int lane, int row, int N) {
+  RowData<R, XC> r;
+  if constexpr (XC) {
+    const uint32_t soff = (uint32_t)row * (uint32_t)N;
+    if constexpr (sizeof(R) == 8) {
+      const abd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(d.rs_y, (uint32_t)lane * 8u, soff * 8u, 0);
+      r.y = __hiloint2double((int)v.y, (int)v.x);
+    } else {
+      r.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d.rs_y, (uint32_t)lane * 4u, soff * 4u, 0));
+    }
+    r.code = __builtin_amdgcn_raw_buffer_load_b8(d.rs_c, (uint32_t)lane, soff, 0);
+  } else {
+    r.v = load_yx<R>(d.rs, (uint32_t)lane * (uint32_t)sizeof(YX<R>), (uint32_t)row * (uint32_t)N * (uint32_t)sizeof(YX<R>));
+  }
+  return r;
+}
+template <typename R, bool XC>
+__device__ __forceinline__ double row_y(const RowData<R, XC>& r) {
+  if constexpr (XC) return (double)r.y;
+  else return (double)r.v.y;
+}
+template <typename R, bool XC>
+__device__ __forceinline__ double row_x(const RowData<R, XC>& r, const double* dict /* LDS */) {
+  if constexpr (XC) return dict[r.code];
+  else return (double)r.v.x;
+}
+
 // 32 gaps (word q: gaps 32 q .. 32 q + 31) of one individual's packed row.  The panels are [64-gap word][individual]
 // arrays of 64-bit words; base = the panel seen as 32-bit halves (wave-uniform), j2 = 2 x the lane's individual: the
 // address is a scalar base + a 32-bit lane offset, no 64-bit vector arithmetic.
@@ -163,42 +236,32 @@ __device__ __forceinline__ DenseChain dense_chain(const ChainPar& p) {
 // What a piece (lane group lg, gaps [g0, g1)) needs from memory before its walk can start, requested as early as possible:
 // the words before g0 (start state), the words of its first gaps, its first gap rows.
 #define ABD_SW 8  // 32-gap words per group of the start-state pass (covers g0 <= 256 in one group)
-template <typename R>
+template <typename R, bool XC>
 struct PieceLoads {
   uint32_t seg_i, seg_v, nxt_i, nxt_v;  // words g0 >> 5 and (g0 >> 5) + 1
-  YX<R> en, es, on, os;             // gap rows of the first even and the first odd gap of the piece (N, S antigen)
+  RowData<R, XC> en, es, on, os;    // gap rows of the first even and the first odd gap of the piece (N, S antigen)
   int wj;                           // ab_s_waner of the lane's individual
 };
 
-// Buffer descriptor of one antigen's panel based at row g0 of lane group lg (wave-uniform: built outside divergent code,
-// or every load through it becomes a waterfall loop)
-template <typename R>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t piece_rsrc(const void* panel, int N, int lg, int g0) {
-  const int64_t row0 = ((int64_t)g0 * N + (int64_t)lg * 64) * (int64_t)sizeof(YX<R>);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(panel)) + row0, 0, -1, 0x00020000);
-}
-
-template <typename R>
-__device__ __forceinline__ void piece_issue_loads(const EvalArgs& a, const __amdgpu_buffer_rsrc_t& rs_n, const __amdgpu_buffer_rsrc_t& rs_s,
+template <typename R, bool XC>
+__device__ __forceinline__ void piece_issue_loads(const EvalArgs& a, const RowDesc<XC>& rs_n, const RowDesc<XC>& rs_s,
                                                   const uint32_t* ibase, const uint32_t* vbase, const int8_t* waner, int lane, int j,
-                                                  int g0, int g1, PieceLoads<R>& pl) {
+                                                  int g0, int g1, PieceLoads<R, XC>& pl) {
   const int N = a.N;
   const int q = g0 >> 5, q_end = (g1 - 1) >> 5;
-  // the rows first: they come from the farthest away
-  const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
-  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);  // G rows of it fit 32 bits (abd_create checks)
+  // the rows first: they come from the farthest away (G rows of a panel fit a 32-bit offset: abd_create checks)
   const int last = g1 - 1 - g0;
   const int re = min(g0 & 1, last), ro = min((g0 & 1) ^ 1, last);  // row (relative to g0) of the first even / odd gap
   if (g0 & 1) {
-    pl.on = load_yx<R>(rs_n, lane_off, (uint32_t)ro * rstride);
-    pl.os = load_yx<R>(rs_s, lane_off, (uint32_t)ro * rstride);
-    pl.en = load_yx<R>(rs_n, lane_off, (uint32_t)re * rstride);
-    pl.es = load_yx<R>(rs_s, lane_off, (uint32_t)re * rstride);
+    pl.on = row_load<R, XC>(rs_n, lane, ro, N);
+    pl.os = row_load<R, XC>(rs_s, lane, ro, N);
+    pl.en = row_load<R, XC>(rs_n, lane, re, N);
+    pl.es = row_load<R, XC>(rs_s, lane, re, N);
   } else {
-    pl.en = load_yx<R>(rs_n, lane_off, (uint32_t)re * rstride);
-    pl.es = load_yx<R>(rs_s, lane_off, (uint32_t)re * rstride);
-    pl.on = load_yx<R>(rs_n, lane_off, (uint32_t)ro * rstride);
-    pl.os = load_yx<R>(rs_s, lane_off, (uint32_t)ro * rstride);
+    pl.en = row_load<R, XC>(rs_n, lane, re, N);
+    pl.es = row_load<R, XC>(rs_s, lane, re, N);
+    pl.on = row_load<R, XC>(rs_n, lane, ro, N);
+    pl.os = row_load<R, XC>(rs_s, lane, ro, N);
   }
   const uint32_t j2 = 2u * (uint32_t)j;
   pl.seg_i = word32(ibase, j2, q, N);
@@ -295,10 +358,11 @@ __device__ __forceinline__ void dense_start_state(uint32_t (&wi)[ABD_SW], uint32
 }
 
 // Walk gaps [g0, g1) of lane group lg: recurrence form (abd.py:288) + likelihood terms into acc.
-template <typename R, bool GRAD>
-__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const __amdgpu_buffer_rsrc_t& rs_n,
-                                           const __amdgpu_buffer_rsrc_t& rs_s, const uint32_t* ibase, const uint32_t* vbase,
-                                           uint32_t j2, PieceLoads<R>& pl, int lane, int g0, int g1, bool wj, double tn, double dn, double ts,
+template <typename R, bool GRAD, bool XC>
+__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const RowDesc<XC>& rs_n,
+                                           const RowDesc<XC>& rs_s, const double* dict_n, const double* dict_s,
+                                           const uint32_t* ibase, const uint32_t* vbase,
+                                           uint32_t j2, PieceLoads<R, XC>& pl, int lane, int g0, int g1, bool wj, double tn, double dn, double ts,
                                            double ds, uint32_t cfn_hi, uint32_t cfs_hi, const double* tab_e2, double c2v,
                                            double (&acc)[16]) {
   const int N = a.N;
@@ -306,13 +370,11 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
   const double c_s = k.c_s, cp_s = k.cp_s, ci_s = k.ci_s, mc_s = k.mc_s, d_n = k.d_n, d_s = k.d_s;
   const double rho_j = wj ? k.rho_s : 1.0;  // abd.py:374
   double hd_s = 0.0;
-  const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(YX<R>);
-  const uint32_t rstride = (uint32_t)N * (uint32_t)sizeof(YX<R>);
   const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
   const int last = g1 - 1 - g0;
   // gap rows through buffer loads: descriptor base = the piece's first row of this lane group, scalar offset = row
   // within the piece, vector offset = the lane's constant -- no vector address arithmetic at all
-  auto ldrow = [&](const __amdgpu_buffer_rsrc_t& rs, int g) { return load_yx<R>(rs, lane_off, (uint32_t)min(g - g0, last) * rstride); };
+  auto ldrow = [&](const RowDesc<XC>& rs, int g) { return row_load<R, XC>(rs, lane, min(g - g0, last), N); };
   int q = g0 >> 5;
   const int q_end = (g1 - 1) >> 5;
   uint32_t seg_i = pl.seg_i, seg_v = pl.seg_v;
@@ -328,7 +390,7 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
   };
 
   // one gap: 0/1 indicators enter as doubles, so the perm switch (abd.py:306) is an fma, not a select
-  auto step = [&](int g, const YX<R>& on, const YX<R>& os) {
+  auto step = [&](int g, const RowData<R, XC>& on, const RowData<R, XC>& os) {
     const uint32_t bit = (uint32_t)g & 31u;
     const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_i, bit, 1u) & 0x3FF00000u;
     const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)seg_v, bit, 1u) & 0x3FF00000u;
@@ -341,10 +403,10 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
     ts = fma_v(rho_j, ts, e_i + e_v);  // unit boosts: temp unused (abd.py:272)
     const double cf_n = hi_to_double(cfn_hi, z_cn), cf_s = hi_to_double(cfs_hi, z_cs);
     // c mu_n = c (perm + temp + init)   abd.py:341 ; c mu_s = c (perm + tinf + tvac + init)   abd.py:389-391
-    const double t_n = fma(mc_n, (double)on.x, fma(ct_n, tn, fma(cf_n, cp_n, ci_n)));
-    const double t_s = fma(mc_s, (double)os.x, fma(c_s, ts, fma(cf_s, cp_s, ci_s)));
+    const double t_n = fma(mc_n, row_x<R, XC>(on, dict_n), fma(ct_n, tn, fma(cf_n, cp_n, ci_n)));
+    const double t_s = fma(mc_s, row_x<R, XC>(os, dict_s), fma(c_s, ts, fma(cf_s, cp_s, ci_s)));
     double h_n = 0.0, h_s = 0.0;
-    obs_pair_scaled<GRAD>(t_n, (double)on.y, d_n, t_s, (double)os.y, d_s, tab_e2, c2v, acc, h_n, h_s);
+    obs_pair_scaled<GRAD>(t_n, row_y<R, XC>(on), d_n, t_s, row_y<R, XC>(os), d_s, tab_e2, c2v, acc, h_n, h_s);
     if (GRAD) {
       acc[A_N_HC] = fma(h_n, cf_n, acc[A_N_HC]);
       acc[A_N_HU] = fma(h_n, tn, acc[A_N_HU]);
@@ -356,7 +418,7 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
 
   // two row buffers per antigen, one for the even and one for the odd gaps; each is refilled right after the step that
   // consumed it, for the gap two on -- across word boundaries, to the end of the piece
-  YX<R> en = pl.en, es = pl.es, on = pl.on, os = pl.os;
+  RowData<R, XC> en = pl.en, es = pl.es, on = pl.on, os = pl.os;
   int g = g0;
   if (g & 1) {
     step(g, on, os);
@@ -495,14 +557,14 @@ __device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, in
 
 // dynamic LDS of the kernel: [CB][2][G+1] power tables, block reduction, 2^(j/1024) table (and at least the scratch of the
 // fused fixed-order sum)
-__host__ __device__ inline size_t abd_dense_lds(int G, int cb) {
+__host__ __device__ inline size_t abd_dense_lds(int G, int cb, bool xc = false) {
   const size_t need = (size_t)cb * 2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
-                      (size_t)ABD_EXP2_TAB * sizeof(double);
+                      (size_t)ABD_EXP2_TAB * sizeof(double) + (xc ? (size_t)2 * ABD_XDICT * sizeof(double) : 0);
   const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
   return need > fin ? need : fin;
 }
 
-template <typename R, int CB, bool GRAD>
+template <typename R, int CB, bool GRAD, bool XC>
 #ifndef ABD_DENSE_MINW
 #define ABD_DENSE_MINW 4
 #endif
@@ -514,6 +576,9 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   double2_t* tabs = reinterpret_cast<double2_t*>(smem);              // [CB][2][G+1]
   double* red = reinterpret_cast<double*>(tabs + CB * 2 * tstride);  // [WAVES][ABD_NOUT]
   double* tab_e2 = red + ABD_WAVES_PER_BLOCK * ABD_NOUT;             // [ABD_EXP2_TAB] 2^(j/1024)
+  double* dict_n = tab_e2 + ABD_EXP2_TAB;                            // XC: [ABD_XDICT] distinct log dilutions, N antigen ...
+  double* dict_s = dict_n + ABD_XDICT;                               // ... and S antigen
+  static_assert(!XC || CB == 1, "the split panels serve launches that evaluate one chain");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -562,6 +627,12 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   double e2v[ABD_EXP2_TAB / ABD_BLOCK];
 #pragma unroll
   for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) e2v[q] = a.exp2_tab[q * ABD_BLOCK + tid];
+  double dv_n = 0.0, dv_s = 0.0;
+  if (XC) {  // (ABD_XDICT == ABD_BLOCK: one entry of each dictionary per thread)
+    static_assert(ABD_XDICT == ABD_BLOCK, "one dictionary entry per thread");
+    if (tid < a.n_dict_n) dv_n = a.dict_n[tid];
+    if (tid < a.n_dict_s) dv_s = a.dict_s[tid];
+  }
 
   // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows} from the table the
   // host built for this launch shape (abd_eval.hip: range_table).  The first 16 ranges of every grid row (the workgroups
@@ -584,15 +655,15 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   // the first piece's memory accesses go out before the tables are built
   const uint32_t* vbase = reinterpret_cast<const uint32_t*>(a.vw);
   const uint32_t* ibase = reinterpret_cast<const uint32_t*>(p.iw);
-  PieceLoads<R> pl;
+  PieceLoads<R, XC> pl;
   int g1 = min(G, g0 + rows_left);
   int j = lg * 64 + lane;
   // lanes past the last individual (only the last lane group has any) sit their piece out: EXEC masks them, so
   // they neither load nor contribute and the residuals need no 0/1 guard factor
   uint32_t wi[ABD_SW], wv[ABD_SW];  // only a range's first piece can start inside an individual's gaps
   const bool first_inside = rows_left > 0 && j < N && g0 > 0;
-  __amdgpu_buffer_rsrc_t rs_n = piece_rsrc<R>(a.yx_n, N, lg, g0), rs_s = piece_rsrc<R>(a.yx_s, N, lg, g0);
-  if (rows_left > 0 && j < N) piece_issue_loads<R>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
+  RowDesc<XC> rs_n = row_desc<R, XC>(a, 0, lg, g0), rs_s = row_desc<R, XC>(a, 1, lg, g0);
+  if (rows_left > 0 && j < N) piece_issue_loads<R, XC>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
   if (first_inside) state_issue_loads(ibase, vbase, 2u * (uint32_t)j, N, g0, wi, wv);
   // sum(i_raw), sum(ab_s_waner) of the chain: kept with the slot's discrete state (Bernoulli(i_raw | p) is on the RAW
   // matrix, abd.py:427; Q2); the first range of a chain carries them into the sums
@@ -616,6 +687,10 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   ABD_STAMP(2);
 #pragma unroll
   for (int q = 0; q < ABD_EXP2_TAB / ABD_BLOCK; ++q) tab_e2[q * ABD_BLOCK + tid] = e2v[q];
+  if (XC) {
+    dict_n[tid] = dv_n;
+    dict_s[tid] = dv_s;
+  }
   ABD_STAMP(3);
 
   double acc[16];
@@ -641,7 +716,7 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
     // ---- one piece: lane group lg, gaps [g0, g1) ----
     rows_left -= g1 - g0;
     if (j < N)
-      dense_walk<R, GRAD>(a, kc, rs_n, rs_s, ibase, vbase, 2u * (uint32_t)j, pl, lane, g0, g1, pl.wj != 0, tn, dn, ts, ds, cfn_hi, cfs_hi, tab_e2, c2v,
+      dense_walk<R, GRAD, XC>(a, kc, rs_n, rs_s, dict_n, dict_s, ibase, vbase, 2u * (uint32_t)j, pl, lane, g0, g1, pl.wj != 0, tn, dn, ts, ds, cfn_hi, cfs_hi, tab_e2, c2v,
                           acc);
     if (rows_left <= 0) break;
     // the range goes on at gap 0 of the next lane group, from the zero state
@@ -651,9 +726,9 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
     j = lg * 64 + lane;
     tn = dn = ts = ds = 0.0;
     cfn_hi = cfs_hi = 0;
-    rs_n = piece_rsrc<R>(a.yx_n, N, lg, g0);
-    rs_s = piece_rsrc<R>(a.yx_s, N, lg, g0);
-    if (j < N) piece_issue_loads<R>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
+    rs_n = row_desc<R, XC>(a, 0, lg, g0);
+    rs_s = row_desc<R, XC>(a, 1, lg, g0);
+    if (j < N) piece_issue_loads<R, XC>(a, rs_n, rs_s, ibase, vbase, p.waner, lane, j, g0, g1, pl);
   }
 
   ABD_STAMP(7);

@@ -27,10 +27,12 @@ hipError_t launch_k(K kernel, dim3 grid, size_t lds, hipStream_t st, const EvalA
 
 template <typename R, int C>
 hipError_t launch_dense_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
-  return grad ? launch_k(abd_dense_kernel<R, C, true>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, C, false>, grid, lds, st, a);
+  return grad ? launch_k(abd_dense_kernel<R, C, true, false>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, C, false, false>, grid, lds, st, a);
 }
 template <typename R>
-hipError_t launch_dense(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+hipError_t launch_dense(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a, bool xc) {
+  if (xc && C == 1)  // one chain per launch and split panels available: R + 1 instead of 2 R bytes per cell and antigen
+    return grad ? launch_k(abd_dense_kernel<R, 1, true, true>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, 1, false, true>, grid, lds, st, a);
   switch (C) {
     case 4: return launch_dense_g<R, 4>(grad, grid, lds, st, a);
     case 2: return launch_dense_g<R, 2>(grad, grid, lds, st, a);
@@ -182,7 +184,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     lds = abd_obs_lds_head(c->G);
   } else if (c->dense) {
     blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate ? 1 : 0), n / cpw);
-    lds = abd_dense_lds(c->G, cpw);
+    lds = abd_dense_lds(c->G, cpw, cpw == 1 && c->xc_ok);
   } else {
     blocks = c->blocks_x;
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);
@@ -257,8 +259,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, pp.st, a)
                                      : launch_obs<double>(grad, grid, lds, pp.st, a);
   else if (c->dense)
-    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, pp.st, a)
-                                     : launch_dense<double>(cpw, grad, grid, lds, pp.st, a);
+    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, pp.st, a, c->xc_ok)
+                                     : launch_dense<double>(cpw, grad, grid, lds, pp.st, a, c->xc_ok);
   else
     le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, pp.st, a)
                                      : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);

@@ -78,6 +78,11 @@ struct AntigenDev {
   int32_t* ptr = nullptr;  // sparse: (N+1)
   int32_t* j = nullptr;    // sparse: individual per obs
   void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
+  // dense, when the antigen has <= 256 distinct log dilutions: the split panels of one-chain launches (abd_dense.hpp: XC)
+  void* od = nullptr;        // [G][N] od in the storage type
+  uint8_t* xc = nullptr;     // [G][N] code of the cell's log dilution
+  double* dict = nullptr;    // [n_dict] the distinct log dilutions
+  int n_dict = 0;
 };
 
 struct ChainSlot {
@@ -108,6 +113,7 @@ struct abd_ctx {
   int G = 0, N = 0, nt = 0, n_chunks = 1;
   int storage = ABD_STORE_F64;
   bool dense = false;
+  bool xc_ok = false;  // dense and both antigens have split panels
   bool ignore_pcr = false;
   int n_slots = 0;
   int n_cu = 256;

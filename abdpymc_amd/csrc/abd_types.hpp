@@ -107,6 +107,15 @@ struct EvalArgs {
   // dense panels, gap-major [G][N] of {od, log_dilution}
   const void* yx_n;
   const void* yx_s;
+  // the same panels split for launches that evaluate one chain (abd_dense.hpp: XC): od [G][N] in the storage type, a
+  // one-byte code per cell into the antigen's dictionary of distinct log dilutions (nullptr: more than 256 distinct values)
+  const void* od_n;
+  const void* od_s;
+  const uint8_t* xc_n;
+  const uint8_t* xc_s;
+  const double* dict_n;
+  const double* dict_s;
+  int32_t n_dict_n, n_dict_s;
   // packed indicator panels [nt][N]
   const uint64_t* vw;
   const uint64_t* pw;  // nullptr = ignore_pcrpos
@@ -148,6 +157,7 @@ struct YX {
 
 
 #define ABD_EXP2_TAB 1024  // entries of the 2^(j/1024) table (8 KB of LDS per workgroup)
+#define ABD_XDICT 256      // distinct log dilutions per antigen the split panels can code (one byte per cell; abd_dense.hpp: XC)
 
 struct Philox4 {
   uint32_t w[4];

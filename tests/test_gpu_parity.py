@@ -426,3 +426,33 @@ def test_more_than_256_gaps_observation_lists_and_deterministics(G, splits, lane
     lp2, g2 = ctx.logp_dlogp(0, theta)
     assert_close(lp2, g2, *O.logp_dlogp(theta, i_raw, w, coh, splits))
     ctx.close()
+
+
+def test_one_chain_launches_read_the_split_panels_and_agree_with_the_pair_panels():
+    """A launch that evaluates ONE chain reads od and a one-byte code of the cell's log dilution (<= 256 distinct values per
+    antigen) instead of {od, log_dilution} pairs: the same numbers to rounding as the batched launch over the pair panels,
+    both within 1e-6 of the oracle; with more distinct dilutions than a byte can code the library stays on the pair panels."""
+    sc = synthetic.make_cohort(333, 97, seed=12)
+    coh = oracle_cohort_from_synth(sc)
+    for many_dilutions in (False, True):
+        if many_dilutions:  # every cell its own dilution: no dictionary of 256 entries holds them
+            rng = np.random.default_rng(1)
+            coh.s.log_dilution[:] = rng.uniform(0.0, 4.0, coh.s.log_dilution.size)
+        ctx = _ctx(coh, (30, 61), n_chains=4)
+        assert ctx.is_dense
+        cells = 97 * 333
+        # algorithmic bytes of a one-chain launch: (8 + 1) vs 16 bytes per cell and antigen
+        nb = ctx.algorithmic_bytes(1)
+        assert (cells * 32 <= nb < cells * 32 + 40000) if many_dilutions else (cells * 18 <= nb < cells * 18 + 40000)
+        st = [_state(coh, 20 + c) for c in range(4)]
+        for c, (_, i_raw, w) in enumerate(st):
+            ctx.set_discrete(c, i_raw, w)
+        thetas = np.array([t for t, _, _ in st])
+        lp4, g4 = ctx.logp_dlogp_batch([0, 1, 2, 3], thetas)  # one launch, pair panels
+        for c in range(4):
+            lp1, g1 = ctx.logp_dlogp(c, thetas[c])  # one chain per launch
+            ref = O.logp_dlogp(thetas[c], st[c][1], st[c][2], coh, (30, 61))
+            assert_close(lp1, g1, *ref)
+            assert_close(lp4[c], g4[c], *ref)
+            assert abs(lp1 - lp4[c]) <= 1e-12 * abs(lp1)
+        ctx.close()

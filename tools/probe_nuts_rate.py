@@ -33,7 +33,8 @@ else:
     sc = synthetic.make_cohort(N, G)
     ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C, storage=os.environ.get("ABD_PROBE_STORAGE", "f64"))
     states = [synthetic.make_chain_state(N, G, c) for c in range(C)]
-    th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+    row = int(os.environ.get("ABD_PROBE_THETA_ROW", "0"))  # 5 with 25 rows: the starting points bench.py's NUTS run uses
+    th0 = np.stack([synthetic.make_thetas(G, 25 if row else 1, c)[row] for c in range(C)])
 for c in range(C):
     ctx.set_discrete(c, *states[c])
 ta = float(os.environ.get("ABD_PROBE_TARGET_ACCEPT", "0.8"))  # closer to 1: smaller steps, longer trees

@@ -425,20 +425,23 @@ __device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& 
     on = ldrow(rs_n, g + 2);
     os = ldrow(rs_s, g + 2);
     ++g;
+    if (g < g1 && (g & 31) == 0) next_word();
   }
-  for (; g + 1 < g1; g += 2) {
-    if ((g & 31) == 0 && g != g0) next_word();
-    step(g, en, es);
-    en = ldrow(rs_n, g + 2);
-    es = ldrow(rs_s, g + 2);
-    step(g + 1, on, os);
-    on = ldrow(rs_n, g + 3);
-    os = ldrow(rs_s, g + 3);
+  // g is even from here on, so a pair of gaps never straddles a 32-gap word: the inner loop walks the pairs of one word
+  // with the word's registers loop-invariant (one flat loop with the word change inside cost two register moves per gap)
+  while (g + 1 < g1) {
+    const int pair_end = min(((g >> 5) + 1) << 5, g1 - 1);  // pairs start below this
+    for (; g < pair_end; g += 2) {
+      step(g, en, es);
+      en = ldrow(rs_n, g + 2);
+      es = ldrow(rs_s, g + 2);
+      step(g + 1, on, os);
+      on = ldrow(rs_n, g + 3);
+      os = ldrow(rs_s, g + 3);
+    }
+    if (g < g1 && (g & 31) == 0) next_word();
   }
-  if (g < g1) {
-    if ((g & 31) == 0 && g != g0) next_word();
-    step(g, en, es);
-  }
+  if (g < g1) step(g, en, es);  // (its word is in place: the loop above changed it, or the piece is this one gap)
   acc[A_S_HD] += wj ? hd_s : 0.0;  // d rho_j / d rho_s = waner_j
 }
 

@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the config's)")
     ap.add_argument("--splits", default="", help="comma separated gap indexes, e.g. 100 or 66,133")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the sweep / compound-step / NUTS section (A/B runs of the kernels: tools/ab_bench.sh)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step region until this much timed work")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -393,7 +394,7 @@ def main():
 
     # ---- the rate a sampling run gets, and the compound step around it (rank 0, N=1 only) ----
     compound, nuts = None, None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_sampler:
         def sweep_ms(theta_rows, n=5):
             ts = []
             for k in range(n):

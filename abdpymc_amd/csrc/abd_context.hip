@@ -258,9 +258,14 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
     HIP_TRY(hipMalloc(&d.yx, yx.size() * sizeof(YX<R>)));
     HIP_TRY(hipMemcpy(d.yx, yx.data(), yx.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
     // the split panels of one-chain launches: od alone + one byte per cell coding its log dilution (assays use a handful of
-    // dilutions; lossless: the dictionary holds the doubles as given)
+    // dilutions; lossless: the dictionary holds the doubles as given).  Lane-group-major: element (g, j) at
+    // [((j / 64) * G + g) * 64 + j % 64], so the rows a wave walks -- 64 individuals, gap after gap -- are one contiguous
+    // stream (a 64-byte code row is half a cache line: in gap-major order its other half belongs to the neighbouring lane
+    // group and was fetched again by that group's wave, 1.29 x the algorithmic bytes at config 5)
     std::vector<double> dict;
-    std::vector<uint8_t> code((size_t)G * N);
+    const size_t n_lg = ((size_t)N + 63) / 64;
+    auto cell_of = [&](size_t g, size_t j) { return ((j / 64) * (size_t)G + g) * 64 + j % 64; };
+    std::vector<uint8_t> code(n_lg * (size_t)G * 64, 0);
     bool fits = true;
     for (size_t k = 0; k < K && fits; ++k) {
       const double x = o.log_dilution[k];
@@ -270,11 +275,12 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
         if (dict.size() == ABD_XDICT) fits = false;
         else dict.push_back(x);
       }
-      if (fits) code[(size_t)o.idx_gap[k] * N + (size_t)o.idx_ind[k]] = (uint8_t)q;
+      if (fits) code[cell_of((size_t)o.idx_gap[k], (size_t)o.idx_ind[k])] = (uint8_t)q;
     }
     if (fits) {
-      std::vector<R> od((size_t)G * N);
-      for (size_t cell = 0; cell < od.size(); ++cell) od[cell] = yx[cell].y;
+      std::vector<R> od(code.size(), (R)0);
+      for (size_t j = 0; j < (size_t)N; ++j)
+        for (size_t g = 0; g < (size_t)G; ++g) od[cell_of(g, j)] = yx[g * N + j].y;
       d.n_dict = (int)dict.size();
       HIP_TRY(hipMalloc(&d.od, od.size() * sizeof(R)));
       HIP_TRY(hipMemcpy(d.od, od.data(), od.size() * sizeof(R), hipMemcpyHostToDevice));

@@ -62,7 +62,8 @@ __device__ __forceinline__ YX<float> load_yx<float>(const __amdgpu_buffer_rsrc_t
 // ---- where a gap row's {od, log_dilution} comes from ----
 // XC = false: the pair panel, [G][N] of {od, log_dilution} in the storage type: 2 R bytes per cell and antigen.
 // XC = true:  the split panels of a launch that evaluates ONE chain and therefore reads every byte for that chain alone (a
-//             NUTS chain's leapfrogs, abd.py:922; BASELINE config 5): od [G][N] in the storage type + a one-byte code per
+//             NUTS chain's leapfrogs, abd.py:922; BASELINE config 5): od [lane group][G][64] in the storage type (the rows a
+//             wave walks are one contiguous stream) + a one-byte code per
 //             cell into the antigen's dictionary of distinct log dilutions (assays use a handful of dilutions; abd_create
 //             builds the code panel when an antigen has <= 256 distinct values) -- R + 1 bytes per cell and antigen, lossless;
 //             the dictionary (<= 2 KB) sits in LDS.  Four independent chains at config 3 are bound by these bytes.
@@ -93,12 +94,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void* base, int6
 // (built outside divergent code, or every load through a descriptor becomes a waterfall loop)
 template <typename R, bool XC>
 __device__ __forceinline__ RowDesc<XC> row_desc(const EvalArgs& a, int antigen, int lg, int g0) {
-  const int64_t cell0 = (int64_t)g0 * a.N + (int64_t)lg * 64;
   RowDesc<XC> d;
-  if constexpr (XC) {
+  if constexpr (XC) {  // lane-group-major: [lane group][gap][64]
+    const int64_t cell0 = ((int64_t)lg * a.G + g0) * 64;
     d.rs_y = rsrc_at(antigen ? a.od_s : a.od_n, cell0 * (int64_t)sizeof(R));
     d.rs_c = rsrc_at(antigen ? a.xc_s : a.xc_n, cell0);
-  } else {
+  } else {             // gap-major: [gap][individual]
+    const int64_t cell0 = (int64_t)g0 * a.N + (int64_t)lg * 64;
     d.rs = rsrc_at(antigen ? a.yx_s : a.yx_n, cell0 * (int64_t)sizeof(YX<R>));
   }
   return d;
@@ -108,7 +110,7 @@ template <typename R, bool XC>
 __device__ __forceinline__ RowData<R, XC> row_load(const RowDesc<XC>& d, int lane, int row, int N) {
   RowData<R, XC> r;
   if constexpr (XC) {
-    const uint32_t soff = (uint32_t)row * (uint32_t)N;
+    const uint32_t soff = (uint32_t)row * 64u;
     if constexpr (sizeof(R) == 8) {
       const abd_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(d.rs_y, (uint32_t)lane * 8u, soff * 8u, 0);
       r.y = __hiloint2double((int)v.y, (int)v.x);

@@ -79,8 +79,8 @@ struct AntigenDev {
   int32_t* j = nullptr;    // sparse: individual per obs
   void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
   // dense, when the antigen has <= 256 distinct log dilutions: the split panels of one-chain launches (abd_dense.hpp: XC)
-  void* od = nullptr;        // [G][N] od in the storage type
-  uint8_t* xc = nullptr;     // [G][N] code of the cell's log dilution
+  void* od = nullptr;        // [lane group][G][64] od in the storage type (lane-group-major)
+  uint8_t* xc = nullptr;     // [lane group][G][64] code of the cell's log dilution
   double* dict = nullptr;    // [n_dict] the distinct log dilutions
   int n_dict = 0;
 };

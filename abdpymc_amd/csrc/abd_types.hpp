@@ -107,7 +107,7 @@ struct EvalArgs {
   // dense panels, gap-major [G][N] of {od, log_dilution}
   const void* yx_n;
   const void* yx_s;
-  // the same panels split for launches that evaluate one chain (abd_dense.hpp: XC): od [G][N] in the storage type, a
+  // the same panels split for launches that evaluate one chain (abd_dense.hpp: XC): od [lane group][G][64] in the storage type, a
   // one-byte code per cell into the antigen's dictionary of distinct log dilutions (nullptr: more than 256 distinct values)
   const void* od_n;
   const void* od_s;

@@ -54,7 +54,8 @@ def _month_index(period: str) -> int:
 class TiterData:
     """OD, PCR+ and vaccination data of a cohort (abd.py:46-221)."""
 
-    def __init__(self, t0: str, s: AntigenTiterData, n: AntigenTiterData, vacs, pcrpos, n_gaps: int, n_inds: int) -> None:
+    def __init__(self, t0: str, s: AntigenTiterData, n: AntigenTiterData, vacs, pcrpos, n_gaps: int, n_inds: int,
+                 record_ids=None, ageenroll=None) -> None:
         self.t0 = str(t0).strip()
         self.s = s
         self.n = n
@@ -68,13 +69,19 @@ class TiterData:
         self.n_gaps = int(n_gaps)  # max(df.elapsed_months) + 1   abd.py:101
         self.n_inds = int(n_inds)  # max(df.individual_i) + 1     abd.py:102
         self.coords = dict(ind=np.arange(self.n_inds), gap=np.arange(self.n_gaps))  # abd.py:126
+        # record id of every individual in order of first appearance in the table (abd.py:104-110); not used by the model
+        self.record_ids = None if record_ids is None else np.asarray(record_ids)
+        if ageenroll is not None:  # optional enrollment ages keyed by record id (abd.py:128-131); not used by the model
+            if self.record_ids is None:
+                raise ValueError("ageenroll needs the table's record_id column")
+            self.ageenroll = np.array([ageenroll[record_id] for record_id in self.record_ids])
 
     def __repr__(self) -> str:
         return f"TiterData(t0={self.t0}, n_inds={self.n_inds})"
 
     @classmethod
     def from_disk(cls, directory: str) -> "TiterData":
-        """Read df.csv, vacs.txt, pcrpos.txt and t0.txt (abd.py:171-202)."""
+        """Read df.csv, vacs.txt, pcrpos.txt, t0.txt and, where present, individuals.csv (abd.py:171-202)."""
         import pandas as pd
 
         def path(x):
@@ -83,14 +90,18 @@ class TiterData:
         df = pd.read_csv(path("df.csv"), index_col=0)
         vacs = np.loadtxt(path("vacs.txt"))
         pcrpos = np.loadtxt(path("pcrpos.txt"))
+        try:  # enrollment ages, one "record_id,age" row per individual, no header (abd.py:189-194)
+            ageenroll = pd.read_csv(path("individuals.csv"), header=None, index_col=0).squeeze("columns")
+        except FileNotFoundError:
+            ageenroll = None
         if vacs.shape != pcrpos.shape:
             raise ValueError("vacs and pcrpos are different shapes")
         with open(path("t0.txt"), "r") as fobj:
             t0 = fobj.readline().strip()
-        return cls.from_frame(t0, df, vacs, pcrpos)
+        return cls.from_frame(t0, df, vacs, pcrpos, ageenroll=ageenroll)
 
     @classmethod
-    def from_frame(cls, t0: str, df, vacs, pcrpos) -> "TiterData":
+    def from_frame(cls, t0: str, df, vacs, pcrpos, ageenroll=None) -> "TiterData":
         """Split the long table by measurement code (abd.py:82-98)."""
 
         def antigen(ag, code):
@@ -105,7 +116,11 @@ class TiterData:
 
         n_gaps = int(df["elapsed_months"].max()) + 1
         n_inds = int(df["individual_i"].max()) + 1
-        return cls(t0, antigen("s", MEASUREMENT_S), antigen("n", MEASUREMENT_N), vacs, pcrpos, n_gaps, n_inds)
+        record_ids = None
+        if "record_id" in df.columns:
+            record_ids = df[["individual_i", "record_id"]].drop_duplicates()["record_id"].to_numpy()
+        return cls(t0, antigen("s", MEASUREMENT_S), antigen("n", MEASUREMENT_N), vacs, pcrpos, n_gaps, n_inds,
+                   record_ids=record_ids, ageenroll=ageenroll)
 
     @classmethod
     def from_arrays(cls, n_gaps, n_inds, s_obs, n_obs, vacs, pcrpos, t0: str = "2020-05") -> "TiterData":

@@ -188,7 +188,7 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
     i_raw = pt["i_raw"].astype(np.int8)
     waner = pt["ab_s_waner"].astype(np.int8)
     ctx.set_discrete(chain, i_raw, waner)
-    q = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # start jitter: U(-0.1, 0.1); pm.sample's 'jitter+adapt_diag' draws U(-1, 1)
+    q = model.ravel(pt) + rng.uniform(-1, 1, size=len(THETA_NAMES))  # start jitter U(-1, 1) on the value variables: pm.sample's default init 'jitter+adapt_diag'
 
     def fn(x):
         return ctx.logp_dlogp(chain, x)
@@ -297,7 +297,7 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
     for c in range(chains):
         rng = np.random.default_rng([seed, chain_offset + c])
         ctx.set_discrete(c, pt["i_raw"].astype(np.int8), pt["ab_s_waner"].astype(np.int8))
-        q0[c] = model.ravel(pt) + 0.1 * rng.uniform(-1, 1, size=len(THETA_NAMES))  # start jitter: U(-0.1, 0.1); pm.sample's 'jitter+adapt_diag' draws U(-1, 1)
+        q0[c] = model.ravel(pt) + rng.uniform(-1, 1, size=len(THETA_NAMES))  # start jitter U(-1, 1) on the value variables: pm.sample's default init 'jitter+adapt_diag'
     smp = ctx.sampler(np.arange(chains), q0, tune=tune, seed=seed, target_accept=target_accept,
                       max_treedepth=max_treedepth, gibbs=True, accumulate=True, chain_offset=chain_offset,
                       dense_metric=dense_metric)

@@ -108,3 +108,28 @@ def test_recurrence_matches_reference_simulation(expect):
     s = e["init"] + O.perm_response(inf + vac, e["perm"])[:, 0] + ts
     np.testing.assert_allclose(n, e["n"], rtol=1e-13)
     np.testing.assert_allclose(s, e["s"], rtol=1e-13)
+
+
+def test_optional_individuals_csv_gives_enrollment_ages(golden_dir, tmp_path):
+    """abd.py:189-194, 128-131: `individuals.csv` (record_id,age rows, no header) is optional; when present the ages are
+    ordered like the individuals (record ids in order of first appearance in the table, abd.py:104-110)."""
+    import shutil
+
+    import pandas as pd
+
+    src = os.path.join(golden_dir, "test_cohort")
+    td0 = TiterData.from_disk(src)
+    assert not hasattr(td0, "ageenroll") and len(td0.record_ids) == td0.n_inds  # (the shipped cohorts have no such file)
+    df = pd.read_csv(os.path.join(src, "df.csv"), index_col=0)
+    pairs = df[["individual_i", "record_id"]].drop_duplicates()
+    assert list(pairs["record_id"]) == list(td0.record_ids)
+    d = tmp_path / "cohort"
+    shutil.copytree(src, d)
+    ages = {int(r): 20.0 + 1.5 * k for k, r in enumerate(sorted(td0.record_ids))}
+    with open(d / "individuals.csv", "w") as f:
+        for r in sorted(ages, reverse=True):  # file order differs from table order
+            f.write(f"{r},{ages[r]}\n")
+    td = TiterData.from_disk(str(d))
+    assert td.ageenroll.shape == (td.n_inds,)
+    assert [ages[int(r)] for r in td.record_ids] == list(td.ageenroll)
+    assert td.n_gaps == td0.n_gaps and np.array_equal(td.vacs, td0.vacs)

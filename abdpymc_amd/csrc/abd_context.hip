@@ -343,8 +343,6 @@ void free_ctx(abd_ctx* c) {
   if (c->vw) (void)hipFree(c->vw);
   if (c->pw) (void)hipFree(c->pw);
   if (c->exp2_tab) (void)hipFree(c->exp2_tab);
-  for (auto& rt : c->range_tables)
-    if (rt.dev) (void)hipFree(rt.dev);
   if (c->stage_gn) (void)hipFree(c->stage_gn);
   for (auto& s : c->slots) {
     if (s.rw) (void)hipFree(s.rw);
@@ -451,6 +449,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   // the dense kernel addresses the gap rows of a piece (up to G of them) with a 32-bit scalar offset (abd_dense.hpp);
   // beyond 2^28 cells (fp64; 2^29 in fp32 storage) per GPU the cohort takes the observation-list kernels instead
   if ((int64_t)N * (d->storage == ABD_STORE_F32 ? 8 : 16) * (G + 2) >= ((int64_t)1 << 32)) c->dense = false;
+  // ... and splits the (lane group, gap) plane by 32-bit arithmetic: row / G by a 32-bit reciprocal is exact below 2^32 / G
+  // rows (abd_types.hpp: EvalArgs::rg_*; 6.8 M individuals at 200 gaps, 1 M at 512 -- beyond the limit above anyway)
+  if ((uint64_t)c->n_lg * (uint64_t)G * (uint64_t)G >= (1ull << 32)) c->dense = false;
   if (env_int("ABD_FORCE_SPARSE", 0)) c->dense = false;
   c->ignore_pcr = d->pcrpos == nullptr;
   c->n_slots = d->n_chain_slots;

@@ -639,21 +639,28 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
     if (tid < a.n_dict_s) dv_s = a.dict_s[tid];
   }
 
-  // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows} from the table the
-  // host built for this launch shape (abd_eval.hip: range_table).  The first 16 ranges of every grid row (the workgroups
-  // that may carry a fused sum; one range per workgroup only: CB == 4) are fin_rows shorter, the others share the
-  // difference.  The split depends only on (grid.x, CB), never on the chains of the launch or on whether a sum is
-  // actually carried, so results are bit-identical either way.
-  const int4* rtab = reinterpret_cast<const int4*>(a.range_tab) + (int64_t)blk * NSUB;
-  const int4 rt = rtab[sub];
-  int lg = rt.x, g0 = rt.y, rows_left = rt.z;
+  // this wave's range of the flattened (lane group, gap) plane: {first lane group, first gap, rows}, worked out from the
+  // launch shape's split (abd_eval.hip: range_split; scalar arithmetic, nothing to wait for).  The first 16 ranges of every
+  // grid row (the workgroups that may carry a fused sum; one range per workgroup only: CB == 4) are fin_rows shorter, the
+  // others share the difference.  The split depends only on (grid.x, CB), never on the chains of the launch or on whether
+  // a sum is actually carried, so results are bit-identical either way.
+  auto range_start = [&](int r) { return r * a.rg_base + min(r, a.rg_extra) - a.rg_e_fin * min(r, a.rg_n_short); };
+  auto range_of = [&](int r, int& r_lg, int& r_g0, int& r_rows) {
+    const int pos = range_start(r);
+    r_lg = G > 1 ? (int)__umulhi((uint32_t)pos, a.rg_g_magic) : pos;  // pos / G
+    r_g0 = pos - r_lg * G;
+    r_rows = range_start(r + 1) - pos;
+  };
+  int lg, g0, rows_left;
+  range_of(blk * NSUB + sub, lg, g0, rows_left);
   // power-table entries this workgroup reads: up to the largest start gap of its ranges
   int n_entries = rows_left > 0 ? g0 + 1 : 0;
 #pragma unroll
   for (int s = 0; s < NSUB; ++s)
     if (NSUB > 1 && s != sub) {
-      const int4 o = rtab[s];
-      n_entries = max(n_entries, o.z > 0 ? o.y + 1 : 0);
+      int o_lg, o_g0, o_rows;
+      range_of(blk * NSUB + s, o_lg, o_g0, o_rows);
+      n_entries = max(n_entries, o_rows > 0 ? o_g0 + 1 : 0);
     }
   ABD_STAMP(1);
 
@@ -706,7 +713,15 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   const double c2v = to_vgpr(ABD_EXP2_C2);
   const double2_t* tab_n = tabs + (c * 2 + 0) * tstride;
   const double2_t* tab_s = tabs + (c * 2 + 1) * tstride;
-  __syncthreads();
+  // With one range per workgroup-wave and chain (NSUB == 1) a wave reads only the power tables it filled itself: its start
+  // state needs no workgroup barrier, only its own LDS writes to have landed; the barrier (the 2^(j/1024) table is filled by
+  // all waves together) then comes after the start state, when the waves have drifted apart anyway.
+  if (NSUB == 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
   ABD_STAMP(4);
 
   // state at the end of gap g0 - 1 of the first piece: the dense design (abd.py:258-274) summed over earlier exposures
@@ -715,6 +730,7 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   ABD_STAMP(5);
   if (first_inside)
     dense_start_state(wi, wv, ibase, vbase, 2u * (uint32_t)j, N, g0, tab_n, tab_s, pl.wj != 0, tn, dn, ts, ds, cfn_hi, cfs_hi);
+  if (NSUB == 1) __syncthreads();
   ABD_STAMP(6);
 
   while (rows_left > 0) {

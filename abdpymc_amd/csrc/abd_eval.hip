@@ -89,35 +89,18 @@ int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
 
 // The ranges of a dense launch of `blocks` workgroups x `nsub` ranges each: equal shares (+-1) of the n_lg x G rows; with
 // one range per workgroup (nsub == 1) the first ABD_MAX_BATCH ranges -- the workgroups that may carry the fused
-// fixed-order sum of an earlier launch -- are fin_rows shorter and the others share the difference.
-int range_table(abd_ctx* c, int blocks, int nsub, const int32_t** out) {
-  std::lock_guard<std::mutex> lock(c->range_mutex);
-  for (const auto& rt : c->range_tables)
-    if (rt.blocks == blocks && rt.nsub == nsub) {
-      *out = rt.dev;
-      return ABD_OK;
-    }
+// fixed-order sum of an earlier launch -- are fin_rows shorter and the others share the difference.  The kernel works its
+// range out from these five numbers (abd_types.hpp: EvalArgs::rg_*).
+void range_split(const abd_ctx* c, int blocks, int nsub, EvalArgs& a) {
   const int64_t rows_total = (int64_t)c->n_lg * c->G, n_ranges = (int64_t)blocks * nsub;
   const int64_t n_short = nsub == 1 ? std::min<int64_t>(ABD_MAX_BATCH, n_ranges) : 0;
   const int64_t e_fin = (nsub == 1 && (rows_total + n_short * c->fin_rows) / n_ranges >= 2 * c->fin_rows) ? c->fin_rows : 0;
   const int64_t virt = rows_total + n_short * e_fin;
-  auto start = [&](int64_t r) { return r * virt / n_ranges - e_fin * std::min(r, n_short); };
-  std::vector<int32_t> tab((size_t)n_ranges * 4);
-  for (int64_t r = 0; r < n_ranges; ++r) {
-    const int64_t pos = start(r), end = start(r + 1);
-    tab[(size_t)r * 4 + 0] = (int32_t)(pos / c->G);
-    tab[(size_t)r * 4 + 1] = (int32_t)(pos % c->G);
-    tab[(size_t)r * 4 + 2] = (int32_t)std::max<int64_t>(0, end - pos);
-    tab[(size_t)r * 4 + 3] = 0;
-  }
-  abd_ctx::RangeTable rt;
-  rt.blocks = blocks;
-  rt.nsub = nsub;
-  HIP_TRY(hipMalloc(&rt.dev, tab.size() * sizeof(int32_t)));
-  HIP_TRY(hipMemcpy(rt.dev, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  c->range_tables.push_back(rt);
-  *out = rt.dev;
-  return ABD_OK;
+  a.rg_base = (int32_t)(virt / n_ranges);
+  a.rg_extra = (int32_t)(virt % n_ranges);
+  a.rg_e_fin = (int32_t)e_fin;
+  a.rg_n_short = (int32_t)n_short;
+  a.rg_g_magic = c->G > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)c->G - 1) / (uint64_t)c->G) : 0u;
 }
 
 // Which of the context's streams can have kernels on the device at the same time?  HIP multiplexes its streams over a few
@@ -191,7 +174,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   }
   if (blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: grid %d exceeds partial rows %d", blocks, c->blocks_max);
   if (c->dense && !lanes)
-    if (int rrc = range_table(c, blocks, ABD_WAVES_PER_BLOCK / cpw, &a.range_tab)) return rrc;
+    range_split(c, blocks, ABD_WAVES_PER_BLOCK / cpw, a);
   dim3 grid(blocks, n / cpw);
   int pi = 0;
   if (force_pipe >= 0) {

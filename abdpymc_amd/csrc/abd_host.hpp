@@ -129,14 +129,6 @@ struct abd_ctx {
   uint64_t* vw = nullptr;  // [nt][N]
   uint64_t* pw = nullptr;  // [nt][N]
   double* exp2_tab = nullptr;  // dense cohorts: 2^(j/1024) (abd_dense.hpp)
-  // dense kernel: how a launch shape (grid.x, ranges per workgroup) cuts the (lane group, gap) plane into ranges, built on
-  // first use and kept: {first lane group, first gap, rows, 0} per range
-  struct RangeTable {
-    int blocks = 0, nsub = 0;
-    int32_t* dev = nullptr;
-  };
-  std::vector<RangeTable> range_tables;
-  std::mutex range_mutex;  // range_table() may be reached from several sampler threads
   int8_t* stage_gn = nullptr;  // (G, N) upload staging for i_raw
   std::vector<ChainSlot> slots;
   // A pipe = a HIP stream with its own pair of partial buffers and its own pending fixed-order sum.  Pipe 0 is

@@ -122,7 +122,12 @@ struct EvalArgs {
 #ifdef ABD_STAMPS
   unsigned long long* stamps;  // diagnostic build: [grid.x][16] s_memrealtime at phase boundaries
 #endif
-  const int32_t* range_tab;  // dense kernel: {first lane group, first gap, rows, 0} of every range of this launch shape
+  // dense kernel: how this launch shape cuts the (lane group, gap) plane into ranges (abd_eval.hip: range_split): range r
+  // starts at row r base + min(r, extra) - e_fin min(r, n_short) of the flattened plane; row / G by g_magic = ceil(2^32 / G)
+  // (exact below 2^32 / G rows: abd_create checks).  Closed form, not a table: a table is one more dependent memory
+  // round trip in front of everything else a workgroup loads
+  int32_t rg_base, rg_extra, rg_e_fin, rg_n_short;
+  uint32_t rg_g_magic;
   const double* exp2_tab;  // dense kernel: 2^(j/1024), j = 0..1023, correctly rounded (copied to LDS per workgroup)
   double* partials;    // [n_chains][grid.x][ABD_NOUT]
   // dense kernel only: the fixed-order sum of the PREVIOUS launch's partials, done by the first

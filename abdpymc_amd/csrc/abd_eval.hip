@@ -166,7 +166,9 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     blocks = c->ob_n + c->ob_s + c->ob_c;
     lds = abd_obs_lds_head(c->G);
   } else if (c->dense) {
-    blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate ? 1 : 0), n / cpw);
+    // the last launch of a batch of stream-ordered steps ends alone on the chip: it gets the grid of a launch that has the
+    // chip to itself (one wave per SIMD issues at half the rate; a K = 20 region 376 -> 373 us; a longer tail did not pay)
+    blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate && c->steps_behind != 0 ? 1 : 0), n / cpw);
     lds = abd_dense_lds(c->G, cpw, cpw == 1 && c->xc_ok);
   } else {
     blocks = c->blocks_x;
@@ -438,8 +440,12 @@ int abd_logp_dlogp_many(abd_ctx* c, int32_t n_steps, int32_t n, const int32_t* c
   const size_t per_step = (size_t)n * ABD_N_THETA;
   for (int s0 = 0; s0 < n_steps; s0 += kResultSlots) {  // windows of the result ring
     const int s1 = std::min(n_steps, s0 + kResultSlots);
-    for (int k = s0; k < s1; ++k)
-      if (int rc = enqueue_slot(c, k - s0, n, chains, theta + (size_t)k * per_step, grad != nullptr, true)) return rc;
+    for (int k = s0; k < s1; ++k) {
+      c->steps_behind = n_steps - 1 - k;
+      const int rc = enqueue_slot(c, k - s0, n, chains, theta + (size_t)k * per_step, grad != nullptr, true);
+      c->steps_behind = -1;
+      if (rc) return rc;
+    }
     // the results land in mapped host memory slot by slot: queue the pending sums and the joins, then take every step's
     // result as soon as its tag shows -- the host-side assembly of the early steps overlaps the late steps' kernels
     HIP_TRY(hipSetDevice(c->device));

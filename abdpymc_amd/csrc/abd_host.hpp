@@ -164,6 +164,7 @@ struct abd_ctx {
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;
+  int steps_behind = -1;  // abd_logp_dlogp_many: steps still to be queued behind the one being queued (-1: unknown)
   double prior_const = 0.0;
   double* h_out = nullptr;     // pinned + mapped: [kResultSlots + n_sync_slots][n_slots][ABD_NOUT]
   double* d_out = nullptr;     // device view of h_out

@@ -143,28 +143,40 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
 int probe_stream_queues(abd_ctx* c) {
   if (c->n_queues > 0) return ABD_OK;
   HIP_TRY(hipSetDevice(c->device));
-  unsigned long long* d = nullptr;
-  HIP_TRY(hipMalloc(&d, (size_t)kMaxPipes * 2 * sizeof(unsigned long long)));
+  // Candidates: the context's streams plus as many spare ones.  HIP hands its hardware queues to streams in creation order
+  // across the whole process, so the context's 8 streams rarely sit on them evenly (3 + 2 + 2 + 1 on this stack): after the
+  // probe, streams of over-subscribed queues are exchanged for spare streams of under-subscribed ones, so that eight units
+  // are two per queue, not three on one (the queue with the most units sets the pace of a run).
+  constexpr int kCand = 2 * kMaxPipes;
   const int ns = c->n_streams;
-  // Stream pi's wave stays for 150 + 20 pi us, so the waves end at least 20 us apart and a wave that had to wait for a
+  hipStream_t cand[kCand] = {};
+  int n_cand = ns;
+  for (int pi = 0; pi < ns; ++pi) cand[pi] = c->pipe[pi].st;
+  for (; n_cand < ns + kMaxPipes; ++n_cand)
+    if (hipStreamCreateWithFlags(&cand[n_cand], hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+  unsigned long long* d = nullptr;
+  hipError_t le = hipMalloc(&d, (size_t)kCand * 2 * sizeof(unsigned long long));
+  // Stream k's wave stays for 150 + 20 k us, so the waves end at least 20 us apart and a wave that had to wait for a
   // queue starts within a few us of exactly one earlier wave's end: it is behind that one.  A wave that starts while all
   // earlier ones are still there has a queue to itself.  A host hiccup between two launches can make a stream look
   // queued, never the other way round: up to three attempts, the one that finds the most queues counts.
-  int best_nq = 0, best[kMaxPipes] = {};
-  hipError_t le = hipSuccess;
+  int best_nq = 0, best[kCand] = {};
   for (int attempt = 0; attempt < 3 && best_nq < 4 && le == hipSuccess; ++attempt) {
     le = hipDeviceSynchronize();
-    for (int pi = 0; pi < ns && le == hipSuccess; ++pi) {
-      hipLaunchKernelGGL(abd_spin_kernel, dim3(1), dim3(64), 0, c->pipe[pi].st, d + 2 * pi, 15000ull + 2000ull * (unsigned long long)pi);
+    for (int k = 0; k < n_cand && le == hipSuccess; ++k) {
+      hipLaunchKernelGGL(abd_spin_kernel, dim3(1), dim3(64), 0, cand[k], d + 2 * k, 15000ull + 2000ull * (unsigned long long)k);
       le = hipGetLastError();
     }
     if (le == hipSuccess) le = hipDeviceSynchronize();
-    unsigned long long h[kMaxPipes * 2] = {};
-    if (le == hipSuccess) le = hipMemcpy(h, d, sizeof(unsigned long long) * 2 * (size_t)ns, hipMemcpyDeviceToHost);
+    unsigned long long h[kCand * 2] = {};
+    if (le == hipSuccess) le = hipMemcpy(h, d, sizeof(unsigned long long) * 2 * (size_t)n_cand, hipMemcpyDeviceToHost);
     if (le != hipSuccess) break;
-    int nq = 0, q_of[kMaxPipes] = {};
-    unsigned long long busy_until[kMaxPipes] = {};
-    for (int j = 0; j < ns; ++j) {
+    int nq = 0, q_of[kCand] = {};
+    unsigned long long busy_until[kCand] = {};
+    for (int j = 0; j < n_cand; ++j) {
       int q = -1;
       for (int k = 0; k < nq && q < 0; ++k)
         if (h[2 * j] + 300 >= busy_until[k] && h[2 * j] <= busy_until[k] + 800) q = k;  // started 0-8 us after queue k drained
@@ -174,14 +186,46 @@ int probe_stream_queues(abd_ctx* c) {
     }
     if (nq > best_nq) {
       best_nq = nq;
-      std::copy(q_of, q_of + kMaxPipes, best);
+      std::copy(q_of, q_of + kCand, best);
     }
   }
-  (void)hipFree(d);
+  if (d) (void)hipFree(d);
+  const int nq = std::max(1, best_nq);
+  // exchange: pipe 0 is the context's main stream and stays; a pipe whose queue holds more than its share gives its stream
+  // up for a spare one on the queue that holds the fewest
+  if (le == hipSuccess && best_nq > 1) {
+    int load[kCand] = {};
+    bool used[kCand] = {};
+    for (int pi = 0; pi < ns; ++pi) load[best[pi]]++;
+    for (int pi = ns - 1; pi >= 1; --pi) {
+      const int q = best[pi];
+      int q_min = 0;
+      for (int k = 1; k < nq; ++k)
+        if (load[k] < load[q_min]) q_min = k;
+      if (load[q] - load[q_min] < 2) continue;
+      int spare = -1;
+      for (int k = ns; k < n_cand && spare < 0; ++k)
+        if (!used[k] && best[k] == q_min) spare = k;
+      if (spare < 0) continue;
+      used[spare] = true;
+      std::swap(cand[pi], cand[spare]);
+      c->pipe[pi].st = cand[pi];
+      best[pi] = q_min;
+      load[q]--;
+      load[q_min]++;
+    }
+  }
+  for (int k = ns; k < n_cand; ++k)
+    if (cand[k]) (void)hipStreamDestroy(cand[k]);
   HIP_TRY(le);
-  const int nq = best_nq;
-  std::copy(best, best + kMaxPipes, c->queue_of_pipe);
-  c->n_queues = std::max(1, nq);
+  // queue numbers in order of first appearance among the context's streams
+  int renum[kCand], n_seen = 0;
+  std::fill(renum, renum + kCand, -1);
+  for (int pi = 0; pi < ns; ++pi) {
+    if (renum[best[pi]] < 0) renum[best[pi]] = n_seen++;
+    c->queue_of_pipe[pi] = renum[best[pi]];
+  }
+  c->n_queues = std::max(1, n_seen);
   // the sampler's unit u runs on stream pipe_order[u]: streams of different queues first, so that as many units as
   // there are queues really run side by side
   int k = 0;

@@ -185,8 +185,13 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // sizes the dense kernel has a shape for (config 3, evaluations/s seen by NUTS over 150-300 iterations: 8 chains 79 k
   // with units of 1, 112 k with 2; 12 chains 97 k / 88 k / 83 k with 2 / 3 / 4; 16 chains 91 k / 100 k with 2 / 4;
   // 32 chains 100 k / 134 k with 4 / 8)
+  // With leapfrog trains (one chain per unit) and the streams spread evenly over the hardware queues, eight chains run best
+  // as eight units, two per queue: 126 k against 121 k as four units of two; sixteen chains: 145 k as eight units of two,
+  // 155 k as four units of four
+  const bool trains_ok = c->dense && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
   int dense_unit = 1;
   while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
+  if (trains_ok && n <= 8) dense_unit = 1;
   s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
   s->unit = env_int("ABD_SAMPLER_UNIT", s->unit);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
@@ -198,7 +203,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // the starting points through the launch shape the units will use
   rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
   if (!rc && (n + s->unit - 1) / s->unit > 1 && tune_int("ABD_PROBE_QUEUES", 1) != 0) rc = probe_stream_queues(c);
-  s->trains = c->dense && s->unit == 1 && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
+  s->trains = trains_ok && s->unit == 1;
   s->lookahead = std::max(0, std::min(abd_sampler::kTrainRing - 2, tune_int("ABD_TRAIN_LOOKAHEAD", 8)));
   if (!rc && s->trains) rc = train_alloc(s);
   for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {

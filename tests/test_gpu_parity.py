@@ -356,6 +356,10 @@ def test_stream_queue_probe_and_pipes():
     ctx = Context(40, 640, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=4)
     q = ctx.stream_queues()
     assert len(q) == 8 and q[0] == 0 and min(q) == 0
+    # the probe exchanges streams of crowded queues for spare ones on the others: with 4 queues the 8 streams sit 2 + 2 + 2 + 2
+    # (3 + 2 + 2 + 1 as created); allow for a spare stream that was not there to be had
+    counts = [q.count(v) for v in set(q)]
+    assert max(counts) - min(counts) <= 1 or max(counts) <= 3, q
     seen = []
     for v in q:
         if v not in seen:

@@ -315,26 +315,23 @@ __device__ __forceinline__ void dense_start_state(uint32_t (&wi)[ABD_SW], uint32
         any_i |= mi;
         any_v |= mv;
         cnt += __builtin_popcount(mi) + __builtin_popcount(mv);
-        if (__builtin_amdgcn_ballot_w64(mi != 0) != 0) {
-          while (mi) {  // per-lane trip count
-            const int b = __builtin_ctz(mi);
-            mi &= mi - 1;
-            const int idx = rel - b;  // = k + 1 with k = (g0 - 1) - gap of the bit
-            const double2_t pn = tab_n[idx];
-            const double2_t ps = tab_s[idx];
+        // one infection and one vaccination per turn (table entry 0 = {0, 0} stands in where a lane has none left): the
+        // turns of a word are as many as the larger of the two counts, and each turn waits for LDS once
+        if (__builtin_amdgcn_ballot_w64((mi | mv) != 0) != 0) {
+          while (mi | mv) {  // per-lane trip count
+            const int idx_i = mi ? rel - __builtin_ctz(mi) : 0;  // = k + 1 with k = (g0 - 1) - gap of the bit
+            const int idx_v = mv ? rel - __builtin_ctz(mv) : 0;
+            mi &= mi - 1;  // (0 stays 0)
+            mv &= mv - 1;
+            const double2_t pn = tab_n[idx_i];
+            const double2_t ps = tab_s[idx_i];
+            const double2_t pv = tab_s[idx_v];
             tn += pn.x;
             dn += pn.y;
             ts += ps.x;
             ds += ps.y;
-          }
-        }
-        if (__builtin_amdgcn_ballot_w64(mv != 0) != 0) {
-          while (mv) {
-            const int b = __builtin_ctz(mv);
-            mv &= mv - 1;
-            const double2_t ps = tab_s[rel - b];
-            ts += ps.x;
-            ds += ps.y;
+            ts += pv.x;
+            ds += pv.y;
           }
         }
       }

@@ -507,7 +507,7 @@ __device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, in
   tr.sig_s = cur->tr[16];
   abdi::ModelSizes m;
   m.G = a.G;
-  m.dense = 1;
+  m.dense = T.dense;
   m.N = (double)a.N;
   m.cells = (double)a.G * (double)a.N;
   m.Kn = (double)a.K_n;

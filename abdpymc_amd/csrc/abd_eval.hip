@@ -164,7 +164,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   size_t lds;
   if (lanes) {
     blocks = c->ob_n + c->ob_s + c->ob_c;
-    lds = abd_obs_lds_head(c->G);
+    lds = train ? abd_obs_lds_own_sum(c->G) : abd_obs_lds_head(c->G);
   } else if (c->dense) {
     // the last launch of a batch of stream-ordered steps ends alone on the chip: it gets the grid of a launch that has the
     // chip to itself (one wave per SIMD issues at half the rate; a K = 20 region 376 -> 373 us; a longer tail did not pay)
@@ -195,9 +195,12 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
   // a sampler unit's dense launch sums its own partial rows: no second launch
   if (train && pp.on)
     if (int frc = flush_pipe(c, pi)) return frc;  // a train launch sums its own rows: nothing may be pending on its pipe
-  const bool fused_sum = c->dense && !lanes && force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on);
+  // (the observation-lane kernel sums its own rows only in a train launch: for an evaluation the host waits for, the second
+  // launch is as fast -- profiles/README.md, history)
+  const bool fused_sum = force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on) && ((c->dense && !lanes) || (lanes && train));
   if (train) {
-    if (!fused_sum || n != 1) return fail(ABD_ERR_STATE, "internal: a leapfrog-train launch needs a dense cohort, one chain and the kernel's own sum");
+    if (!fused_sum || n != 1) return fail(ABD_ERR_STATE, "internal: a leapfrog-train launch needs one chain and a kernel that sums its own rows");
+    train->dense = c->dense ? 1 : 0;
     train->tag = seq + 1.0;
     a.train = *train;
   }
@@ -374,9 +377,9 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
 
 // One launch of a leapfrog train (abd_types.hpp: TrainArgs; abd_sampler.hip) for `chain` on pipe `pi`: the launch assembles
 // its own result and leaves it in t->rec under t->tag (set here); nothing is kept in the result slots.
-int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms) {
+int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms, double* seqp) {
   const int32_t ch = chain;
-  return enqueue_group(c, 1, &ch, nullptr, true, c->d_out + (size_t)kSyncSlot * c->n_slots * ABD_NOUT, false, pi, &first_terms, nullptr, t);
+  return enqueue_group(c, 1, &ch, nullptr, true, c->d_out + (size_t)kSyncSlot * c->n_slots * ABD_NOUT, false, pi, &first_terms, seqp, t);
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors) {

@@ -225,7 +225,7 @@ int wait_rows(abd_ctx* c, int slot, int n, double tag, hipStream_t st = nullptr)
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
                  int force_pipe = -1, double* seqp = nullptr);
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true);
-int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms);
+int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms, double* seqp = nullptr);
 
 // ---- abd_gibbs.hip
 int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,

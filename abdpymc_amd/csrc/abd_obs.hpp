@@ -12,10 +12,10 @@
 // individuals (the Bernoulli counts n1 = sum i_raw, m1 = sum waner); grid.y = chain of the launch.
 // Each workgroup writes one row of partials[chain][block][16] (zeros where its segment has no term); the
 // fixed-order sum over rows (finalize_chain) is shared with the other kernels.
-// Included by abd_kernels.hpp.
+// Included by abd_eval_kernels.hpp (after abd_dense.hpp, whose leapfrog-train epilogue it shares).
 #pragma once
 
-#include "abd_device.hpp"
+#include "abd_dense.hpp"
 
 // exposures of the set bits of `m` (word t) at or before gap g: sum of tab[g - pos + 1]
 __device__ __forceinline__ void add_bits(uint64_t m, int t, int g, const double2_t* tab, double& u, double& d) {
@@ -37,10 +37,15 @@ __device__ __forceinline__ bool any_bits(uint64_t m, int t, int g) {
   return (m & le) != 0;
 }
 
-// LDS of abd_obs_kernel: two tables of G + 1 entries, [waves][8] wave sums, a flag, and (fused sum) the scratch of the
-// fixed-order sum behind them
+// LDS of abd_obs_kernel: two tables of G + 1 entries, [waves][8] wave sums, a flag
 __host__ __device__ inline size_t abd_obs_lds_head(int G) {
   return (size_t)2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * 8 * sizeof(double) + 16;
+}
+// ... and of a launch that sums its own partial rows (a leapfrog-train launch: the last workgroup's fixed-order sum reuses
+// the tables' space, ABD_FIN_PARTS rows of 16 doubles)
+__host__ __device__ inline size_t abd_obs_lds_own_sum(int G) {
+  const size_t head = abd_obs_lds_head(G), sum = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
+  return head > sum ? head : sum;
 }
 
 template <typename R, bool GRAD, int MT>
@@ -51,8 +56,25 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
   double2_t* tab_ones = tab + tstride;                  // rho_j = 1 for individuals whose S response does not wane
   double* red = reinterpret_cast<double*>(tab_ones + tstride);  // [waves][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const ChainPar& p = a.ch[blockIdx.y];
+  ChainPar p = a.ch[blockIdx.y];
   const int b = blockIdx.x;
+  // leapfrog trains (abd_types.hpp: TrainArgs; one chain per launch): the point was left in device memory by the launch
+  // before this one on the stream, and that launch's record is passed on to the host
+  if (GRAD && a.train.enabled && a.train.use_slot >= 0) {
+    const double* tr = a.train.slots[a.train.use_slot].tr;
+    p.perm_n = tr[1];
+    p.temp_n = tr[2];
+    p.rho_n = tr[3];
+    p.init_n = tr[4];
+    p.perm_s = tr[5];
+    p.rho_s = tr[6];
+    p.init_s = tr[10];
+    p.b_n = tr[11];
+    p.d_n = tr[12];
+    p.b_s = tr[14];
+    p.d_s = tr[15];
+    if (a.train.fwd_rec && b == 0 && wave == ABD_WAVES_PER_BLOCK - 1) train_forward_record(a.train, lane);
+  }
   const int seg = b < a.ob_n ? 0 : (b < a.ob_n + a.ob_s ? 1 : 2);
   double acc[7];
 #pragma unroll
@@ -155,6 +177,37 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
       for (int w = 0; w < ABD_WAVES_PER_BLOCK; ++w) v += red[w * 8 + src];
     }
     double* row = a.partials + ((int64_t)blockIdx.y * gridDim.x + b) * ABD_NOUT;
-    row[tid] = v;  // the fixed-order sum follows as its own launch (abd_finalize_kernel)
+    if (a.fin_count)
+      __hip_atomic_store(row + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another workgroup of THIS launch
+    else
+      row[tid] = v;  // the fixed-order sum follows as its own launch (abd_finalize_kernel)
   }
+  if (!a.fin_count) return;
+
+  // ---- own fixed-order sum (a leapfrog-train launch: the host is not there to queue a second kernel): the workgroup that
+  // counts in last sums the chain's partial rows itself.  Hand-off as in abd_dense_kernel: the row was stored write-through
+  // by 16 lanes of wave 0, wave 0 drains its stores, one lane counts in with a returning agent-scope add, the last
+  // workgroup re-reads the rows with device-coherent loads behind a barrier.
+  int* flag = reinterpret_cast<int*>(red + ABD_WAVES_PER_BLOCK * 8);
+  __syncthreads();
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned int old = __hip_atomic_fetch_add(a.fin_count + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = old + 1u == gridDim.x ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const bool last = flag[0] != 0;  // workgroup-uniform; read before the sum's scratch overwrites the flag
+  __syncthreads();
+  if (!last) return;
+  const double* rows = a.partials + (int64_t)blockIdx.y * gridDim.x * ABD_NOUT;
+  if (GRAD && a.train.enabled) {
+    sum_chain_coherent<ABD_BLOCK>(rows, (int)gridDim.x, reinterpret_cast<double*>(smem), tid);
+    if (wave == 0) train_epilogue(a, reinterpret_cast<double*>(smem), lane);
+  } else {
+    finalize_chain_coherent<ABD_BLOCK>(rows, (int)gridDim.x, a.fin_out + (int64_t)blockIdx.y * ABD_NOUT, reinterpret_cast<double*>(smem), tid,
+                                       a.fin_tag);
+  }
+  if (tid == 0) __hip_atomic_store(a.fin_count + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -25,6 +25,7 @@ struct abd_sampler {
   // the launch queued behind it -- and the host keeps up to `lookahead` launches of a half queued ahead of the record it
   // is waiting for, so a chain's leapfrogs follow each other at the device's pace, not at the host's round trip.
   bool trains = false;
+  bool unit_tags = false;  // the units' launches are tagged from the context's per-unit sequences (several host threads)
   int lookahead = 8;
   static constexpr int kTrainRing = 32;  // records per unit: > lookahead + 1
   struct TrainUnit {
@@ -99,7 +100,8 @@ int train_launch(abd_sampler* s, int u, const double* theta, const double* p_hal
       ta.fwd_tag = t.tags[kp];
     }
   }
-  if (int rc = enqueue_train_launch(c, s->chains[(size_t)u], unit_pipe(c, u), &ta, ht)) return rc;
+  // (units driven by their own host threads tag their launches from their own sequence: abd_host.hpp, unit_seq)
+  if (int rc = enqueue_train_launch(c, s->chains[(size_t)u], unit_pipe(c, u), &ta, ht, s->unit_tags ? &c->unit_seq[(size_t)u] : nullptr)) return rc;
   t.tags[t.prod % abd_sampler::kTrainRing] = ta.tag;
   t.prod += 1;
   t.next_slot = ta.next_slot;
@@ -188,7 +190,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // With leapfrog trains (one chain per unit) and the streams spread evenly over the hardware queues, eight chains run best
   // as eight units, two per queue: 126 k against 121 k as four units of two; sixteen chains: 145 k as eight units of two,
   // 155 k as four units of four
-  const bool trains_ok = c->dense && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
+  const bool trains_ok = (c->dense || c->obs_lanes) && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
   int dense_unit = 1;
   while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
   if (trains_ok && n <= 8) dense_unit = 1;
@@ -361,6 +363,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   // belongs to the CONTEXT, like the result rows kSyncSlot + u the tags are compared against: monotone for the life of
   // those rows, whichever sampler drives them
   while (c->unit_seq.size() < (size_t)n_units) c->unit_seq.push_back((double)(c->unit_seq.size() + 1) * 1099511627776.0);
+  s->unit_tags = T_all > 1;
   HIP_TRY(hipSetDevice(c->device));
   if (int frc = flush_ring(c)) return frc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first

@@ -83,6 +83,8 @@ struct TrainArgs {
   int32_t use_slot;         // >= 0: this launch's point is slots[use_slot]; < 0: `first` below (the host staged it)
   int32_t next_slot;        // where this launch leaves the next point
   int32_t own_record;       // 1: this launch writes its own record to `rec` (no successor is going to pass it on)
+  int32_t dense;            // 1: the sums come from the dense kernel (its sum for d/db is scaled: abd_terms.hpp), 0: observation lists
+  int32_t pad_;
   TrainRecord* fwd_rec;     // use_slot >= 0: the predecessor's record, written by this launch from slots[use_slot] ...
   double fwd_tag;           // ... under the predecessor's tag; nullptr: the predecessor wrote its own
   double inv_mass[ABD_NT];  // diagonal of M^-1

@@ -165,6 +165,12 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
  * re-evaluation are queued behind each other on its stream, and the host polls completion tags -- no unit waits
  * for another one's trees (as PyMC's one process per chain does not), and their launches overlap on the device.
  * What a unit computes depends only on the unit (fixed launch shape), never on the other units or on timing.
+ * Units of ONE chain run leapfrog trains (dense cohorts and observation lists alike; diagonal metric): inside one half
+ * of a tree doubling the launch that evaluates a point also assembles logp and gradient, finishes the leapfrog and leaves
+ * the next point in device memory for the launch the host has already queued behind it, so a chain's leapfrogs follow
+ * each other at the device's pace, not at the host's round trip.  A train run is exactly repeatable and equals the
+ * host-driven one (ABD_SAMPLER_TRAINS=0) to rounding, not bit for bit: the closed forms of the transforms are the
+ * device's exp / log1p there.
  * Cohorts kept as observation lists are bound by the host's two kernel launches per evaluation, so their units are
  * driven by T host threads inside abd_sampler_run (T a power of two <= 8, 4 by default; thread t the units u with
  * u mod T == t: what a thread touches is private to its units); dense cohorts are bound by the device and use the calling
@@ -294,7 +300,7 @@ int abd_n_pipes(abd_ctx* ctx);
  *   ABD_OBS_LANES        by list density     observation lists: 1 = lane-per-observation kernel, 0 = wave-per-individual
  *   ABD_FORCE_SPARSE     0                   1 = keep a dense panel as observation lists (exercises the list kernels)
  *   ABD_GIBBS_V1         0                   1 = dense cohorts sweep with the wave-per-proposal kernel (cross-check)
- *   ABD_DENSE_OWN_SUM    1                   0 = a sampler unit's dense launch is summed by a second launch (same bits)
+ *   ABD_DENSE_OWN_SUM    1                   0 = a sampler unit's launch is summed by a second launch (same bits; no leapfrog trains then)
  *   ABD_SAMPLER_THREADS  1 dense / 4 lists   host threads that drive the native sampler's units (<= 8 are used)
  *   ABD_SAMPLER_UNIT     by cohort           chains per independent unit of the native sampler
  *   ABD_SAMPLER_TRAINS   1                   0 = no leapfrog trains: the host sees every leapfrog before the next is queued

@@ -409,15 +409,25 @@ def test_a_chains_draws_do_not_depend_on_how_the_chains_are_grouped(test_td, mon
         m.close()
         return th, st, states
 
-    th1, st1, s1 = run(5, 1)
-    for n_chains, unit in ((5, 2), (5, 4), (5, 8), (2, 1), (2, 2)):
-        th, st, ss = run(n_chains, unit)
-        np.testing.assert_array_equal(th, th1[:n_chains])
-        np.testing.assert_array_equal(st["gibbs_accepted"], st1["gibbs_accepted"][:n_chains])
+    def same(a, b, n_chains):
+        np.testing.assert_array_equal(b[0], a[0][:n_chains])
+        np.testing.assert_array_equal(b[1]["gibbs_accepted"], a[1]["gibbs_accepted"][:n_chains])
         for c in range(n_chains):
-            np.testing.assert_array_equal(ss[c][0], s1[c][0])
-            np.testing.assert_array_equal(ss[c][1], s1[c][1])
-    assert len({tuple(th1[c, -1]) for c in range(5)}) == 5
+            np.testing.assert_array_equal(b[2][c][0], a[2][c][0])
+            np.testing.assert_array_equal(b[2][c][1], a[2][c][1])
+
+    # evaluations the host assembles (units of one chain would run leapfrog trains, whose closed forms are the device's:
+    # equal to rounding, not bit for bit -- test_observation_list_trains_follow_the_host_driven_chain)
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "0")
+    ref = run(5, 1)
+    for n_chains, unit in ((5, 2), (5, 4), (5, 8), (2, 1), (2, 2)):
+        same(ref, run(n_chains, unit), n_chains)
+    assert len({tuple(ref[0][c, -1]) for c in range(5)}) == 5
+    # leapfrog trains: a chain's draws do not depend on how many chains run beside it
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "1")
+    ref_t = run(5, 1)
+    same(ref_t, run(2, 1), 2)
+    same(ref_t, run(5, 1), 5)
 
 
 def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
@@ -444,9 +454,11 @@ def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
         m.close()
         return th, st, rec, means, states, fb
 
-    ref = run(1, 2)
-    for threads, unit in ((4, 1), (3, 2), (2, 1), (16, 1), (4, 8)):
-        got = run(threads, unit)
+    def check(ref, cases):
+        for threads, unit in cases:
+            compare(ref, run(threads, unit))
+
+    def compare(ref, got):
         np.testing.assert_array_equal(got[0], ref[0])
         for k in ref[1]:
             np.testing.assert_array_equal(got[1][k], ref[1][k], err_msg=k)
@@ -457,6 +469,14 @@ def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
             np.testing.assert_array_equal(got[4][c][0], ref[4][c][0])
             np.testing.assert_array_equal(got[4][c][1], ref[4][c][1])
         assert got[5] == 0
+
+    # evaluations the host assembles: any number of threads, any split into units
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "0")
+    check(run(1, 2), ((4, 1), (3, 2), (2, 1), (16, 1), (4, 8)))
+    # leapfrog trains (units of one chain): any number of threads
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "1")
+    check(run(1, 1), ((4, 1), (2, 1), (16, 1)))
+    monkeypatch.delenv("ABD_SAMPLER_TRAINS")
 
     sc = synthetic.make_cohort(300, 40, seed=4)
 
@@ -551,6 +571,39 @@ def test_units_on_a_dense_cohort_are_deterministic_and_record_like_a_twin_run():
             np.testing.assert_array_equal(rec["i"][c, k], i_ref)
             lp = O.logp_dlogp(th_b[c, k], rec["i_raw"][c, k], rec["ab_s_waner"][c, k], coh, (17,))[0]
             assert abs(lp - st_b["lp"][c, k]) <= 1e-9 * abs(lp)
+
+
+def test_observation_list_trains_follow_the_host_driven_chain(test_td, monkeypatch):
+    """Leapfrog trains on the reference's cohorts (observation lists, units of one chain, the units on their own host threads):
+    the lane-per-observation kernel of a train launch sums its own partial rows and its last workgroup does the leapfrog.
+    Same trees and the same points to rounding as the host-driven chain over the first transitions, exactly repeatable, and
+    no completion wait falls back to a stream synchronise."""
+    from abdpymc_amd.model import model
+
+    C = 4
+
+    def run(trains):
+        monkeypatch.setenv("ABD_SAMPLER_TRAINS", trains)
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", "1")
+        m = model(test_td, splits=(14,), n_chains=C)
+        smp = m.ctx.sampler(np.arange(C), _start(m, C, seed=4), tune=30, seed=7)
+        th, st = smp.run(40)
+        states = [m.ctx.get_discrete(c) for c in range(C)]
+        fb = m.ctx.wait_fallbacks
+        smp.close()
+        m.close()
+        return th, st, states, fb
+
+    t_host, s_host, _, _ = run("0")
+    t_a, s_a, d_a, fb_a = run("1")
+    t_b, s_b, d_b, fb_b = run("1")
+    assert fb_a == 0 and fb_b == 0
+    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a)
+    assert all(np.array_equal(d_a[c][0], d_b[c][0]) and np.array_equal(d_a[c][1], d_b[c][1]) for c in range(C))
+    assert np.isfinite(t_a).all() and (s_a["n_steps"] >= 1).all() and s_a["n_steps"].max() > 3
+    assert np.array_equal(s_a["n_steps"][:, :3], s_host["n_steps"][:, :3])
+    np.testing.assert_allclose(t_a[:, :3], t_host[:, :3], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(s_a["lp"][:, :3], s_host["lp"][:, :3], rtol=1e-9)
 
 
 def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch):

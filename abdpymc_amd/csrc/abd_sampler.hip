@@ -305,17 +305,17 @@ int record_flush_chain(abd_sampler* s, const abd_record* rec, int k, int64_t fir
 }
 
 // stage the current draw of chain k at position `pos` of its chunk (all asynchronous on stream st)
-int record_stage_chain(abd_sampler* s, const abd_record* rec, int k, int64_t pos, hipStream_t st) {
+int record_stage_chain(abd_sampler* s, const abd_record* rec, int k, int64_t pos, hipStream_t st, double* sums = nullptr) {
   abd_ctx* c = s->c;
   const size_t cells = (size_t)c->G * c->N, N = (size_t)c->N;
   const size_t per_var = (size_t)s->n * s->rec_chunk * cells;
   const size_t at = ((size_t)k * s->rec_chunk + pos);
   const int chain = s->chains[(size_t)k];
   const ChainSlot& slot = c->slots[(size_t)chain];
-  if (rec->i || rec->ab_n_mu || rec->ab_s_mu)
+  if (rec->i || rec->ab_n_mu || rec->ab_s_mu || sums)  // (sums: the draw also goes into the device-resident running sums)
     if (int rc = launch_deterministics(c, chain, s->ch[(size_t)k].nuts.q, st, rec->i ? s->d_rec_i8 + per_var + at * cells : (int8_t*)nullptr,
                                        rec->ab_n_mu ? s->d_rec_mu + at * cells : (double*)nullptr,
-                                       rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, nullptr))
+                                       rec->ab_s_mu ? s->d_rec_mu + per_var + at * cells : (double*)nullptr, sums))
       return rc;
   if (rec->i_raw)
     if (int rc = launch_unpack(c, chain, s->d_rec_i8 + at * cells, st)) return rc;
@@ -444,10 +444,24 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
         o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
       }
-      if (draw && s->d_sums)
+    }
+    // the next iteration's first leapfrogs go out BEFORE this iteration's recording is queued: the recording kernels read the
+    // point (by value) and the discrete state, which only the next sweep -- queued after them -- changes, and the host's time
+    // for queueing them (several launches per draw) passes while the device is already at work for the chain
+    const bool last = un.k + 1 == n_iter;
+    if (!last) {
+      for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
+      un.state = EVAL;
+      if (int rc = launch_tree(u)) return rc;
+    }
+    for (int j = un.lo; j < un.hi; ++j) {
+      // running sums and the draw's record share one launch of the Deterministics kernel where both are wanted
+      double* sums = (draw && s->d_sums) ? s->d_sums + (size_t)j * 3 * (size_t)c->G * c->N : nullptr;
+      if (recording) {
+        if (int rc = record_stage_chain(s, rec, j, un.staged, st, sums)) return rc;
+      } else if (sums) {
         if (int rc = accumulate_chain(s, j, st)) return rc;
-      if (recording)
-        if (int rc = record_stage_chain(s, rec, j, un.staged, st)) return rc;
+      }
     }
     if (recording && ++un.staged == s->rec_chunk) {
       for (int j = un.lo; j < un.hi; ++j)
@@ -456,16 +470,13 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
       un.staged = 0;
     }
     un.k += 1;
-    if (un.k == n_iter) {
+    if (last) {
       un.state = DONE;
       if (recording)
         for (int j = un.lo; j < un.hi; ++j)
           if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
-      return ABD_OK;
     }
-    for (int j = un.lo; j < un.hi; ++j) s->ch[(size_t)j].begin();
-    un.state = EVAL;
-    return launch_tree(u);
+    return ABD_OK;
   };
   for (int u = 0; u < n_units; ++u) {
     Unit& un = units[(size_t)u];

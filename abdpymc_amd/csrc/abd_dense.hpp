@@ -660,6 +660,9 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
       n_entries = max(n_entries, o_rows > 0 ? o_g0 + 1 : 0);
     }
   ABD_STAMP(1);
+#ifdef ABD_STAMPS
+  if (a.stamps && wave == 0 && lane == 0 && blockIdx.y == 0) a.stamps[(int64_t)blockIdx.x * 16 + 9] = (unsigned long long)g0;  // (diagnostic)
+#endif
 
   // the first piece's memory accesses go out before the tables are built
   const uint32_t* vbase = reinterpret_cast<const uint32_t*>(a.vw);

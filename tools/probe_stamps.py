@@ -57,6 +57,12 @@ for k, nme in enumerate(names):
 st = acc[-1][0]
 life = st[:, 8] - st[:, 0]
 print("workgroup lifetime (entry -> end) percentiles 5/25/50/75/95/100:", np.round(np.percentile(life, [5, 25, 50, 75, 95, 100]), 2))
+g0s = np.array(arr, dtype=np.float64).reshape(4096, 16)[used][:, 9]
+ss_t = st[:, 6] - st[:, 4]
+for lo, hi in ((0, 1), (1, 50), (50, 100), (100, 150), (150, 1000)):
+    sel = (g0s >= lo) & (g0s < hi)
+    if sel.any():
+        print(f"start gap in [{lo}, {hi}): {int(sel.sum())} workgroups (wave 0), barrier -> start state rebuilt median {np.median(ss_t[sel]):.2f} us, max {ss_t[sel].max():.2f} us; end median {np.median(st[sel, 8]):.2f} us")
 print("entry time percentiles 5/25/50/75/95/100:", np.round(np.percentile(st[:, 0], [5, 25, 50, 75, 95, 100]), 2))
 print("end time percentiles 5/25/50/75/95/100:", np.round(np.percentile(st[:, 8], [5, 25, 50, 75, 95, 100]), 2))
 loop = st[:, 7] - st[:, 6]

@@ -430,9 +430,13 @@ def main():
                         note="gibbs_sweep_ms: one sweep of all chains (median of 5) starting from the bench's fresh random discrete state, "
                              f"before any sampler run ({C} chains x {G * N + N} binary dims); _converged_state: the same on the simulation's own "
                              "infections and parameters; chain_iterations_per_s: abd_sampler_run, first iterations (step size still adapting)")
-        # NUTS as the native sampler runs it (no sweep): step size settles for 15 iterations, then one call of 300 iterations
+        # NUTS as the native sampler runs it (no sweep): step size settles for 15 iterations, then one call of 300 iterations.
+        # Every chain samples the SAME target here (chain 0's discrete state; own start, own random stream), as the chains
+        # of a real run do once they have converged: with a different random discrete state per chain and no sweep the step
+        # sizes -- and with them the tree lengths -- differ several-fold between chains, and the call, which ends with its
+        # longest chain, measures that imbalance rather than the rate (profiles/r03: 89-109 k against 122-133 k)
         for c in range(C):
-            ctx.set_discrete(c, *states[c])
+            ctx.set_discrete(c, *states[0])
         smp = ctx.sampler(chains, thetas[W], tune=10 ** 6, seed=3, gibbs=False)
         smp.run(15)
         n_it = 300  # one call: a run ends with its slowest chain, so short calls would time their idle tails
@@ -445,12 +449,13 @@ def main():
                     leapfrogs_per_iteration_and_chain=round(n_lf / n_it / C, 1),
                     leapfrogs_per_chain=[int(x) for x in np.asarray(st["n_steps"]).reshape(C, -1).sum(axis=1)],
                     us_per_leapfrog_of_a_chain=round(t_n / (n_lf / C) * 1e6, 2),
-                    note="leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only; dense "
+                    note="leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only, every chain on "
+                         "the same discrete state (chain 0's); dense "
                          "cohorts with one chain per unit run leapfrog trains (every launch leaves the next point of the half for the "
                          "launch queued behind it); each chain reads the OD panels for itself, so the rate is bound by "
                          "bytes per evaluation, not by the batched kernel's instruction roof.  Chains are independent: the call "
                          "ends with the chain that had the most leapfrogs (leapfrogs_per_chain), the others idle behind it -- "
-                         "measured 96-123 k evals/s at config 3 over starting points and boxes (profiles/r03)")
+                         "leapfrogs_per_chain shows the spread")
         for c in range(C):
             ctx.set_discrete(c, *states[c])
 

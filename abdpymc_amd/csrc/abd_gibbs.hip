@@ -44,7 +44,11 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
   ga.stats = stats_dev;
   if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, 8 * sizeof(unsigned long long), st));
   const int rbytes = c->storage == ABD_STORE_F32 ? 4 : 8;
-  const int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
+  int nw2 = abd_g2_waves(c->G, rbytes);  // waves of a workgroup = of a CU: as many as its LDS holds, 12 at most
+  // a one-chain sweep is a sampler unit's: with 8 waves per CU (2 per SIMD) the other units' evaluation kernels find room
+  // beside it (12 waves x 168 registers fill the CU's register file); the sweep itself 0.39 -> 0.41 ms, the compound
+  // iteration of 4 chains at config 3 6.17 -> 5.90 ms.  Trajectories do not depend on the launch shape.
+  if (m == 1) nw2 = std::max(4, std::min(nw2, tune_int("ABD_G2_WAVES_ONE", 8)));
   if (c->dense && !c->gibbs_v1 && nw2 >= 4 && c->nt <= ABD_MAXT) {  // (the lane-per-proposal kernel is built for <= 256 gaps)
     // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
     // per chain

@@ -2,7 +2,7 @@
 //
 // Replaces, for the joint-logp path only, what PyMC/PyTensor compile out of abdpymc.model()
 // (reference abdpymc/abd.py:396-469): the closed-form prior terms + transform Jacobians are evaluated
-// here on the host (17 scalars), the O(G*N) data term on the device (abd_kernels.hpp).
+// here on the host (17 scalars), the O(G*N) data term on the device (abd_dense.hpp, abd_obs.hpp, abd_sparse.hpp).
 #include "abd_host.hpp"
 #include "abd_small.hpp"
 

@@ -1,5 +1,5 @@
 // abd_gibbs.hpp -- one binary Gibbs-Metropolis sweep over [i_raw, ab_s_waner] on the device
-// (included by abd_kernels.hpp after the shared helpers and the sparse kernel's `responses`).
+// (included by abd_gibbs.hip after the shared helpers and the sparse kernel's `responses`).
 //
 // What it replaces: PyMC's BinaryGibbsMetropolis.astep on the two discrete variables of the model
 // (reference abd.py:427, 373; step assignment made by pm.sample, abd.py:922): shuffle all G*N + N binary

@@ -1,5 +1,5 @@
 // abd_gibbs2.hpp -- the binary Gibbs-Metropolis sweep for DENSE panels, speculative lane-per-proposal form
-// (included by abd_kernels.hpp after abd_gibbs.hpp, whose Philox stream, GibbsArgs and helpers it shares).
+// (included by abd_gibbs.hip after abd_gibbs.hpp, whose Philox stream, GibbsArgs and helpers it shares).
 //
 // Same sweep as abd_gibbs_kernel (PyMC's BinaryGibbsMetropolis on [i_raw, ab_s_waner], abd.py:427, 373, 922; see
 // abd_gibbs.hpp for why one individual's proposals can run on their own and in which random order), same random

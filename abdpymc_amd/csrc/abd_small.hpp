@@ -4,7 +4,7 @@
 
 #include "abd_device.hpp"
 
-// One wave that stays on the device for `ticks` of the 100 MHz s_memrealtime counter and says when (abd_capi.hip:
+// One wave that stays on the device for `ticks` of the 100 MHz s_memrealtime counter and says when (abd_context.hip:
 // probe_stream_queues -- which of the context's HIP streams can have kernels on the device at the same time)
 __global__ void abd_spin_kernel(unsigned long long* out, unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -19,7 +19,7 @@
 #define ABD_WAVES_PER_BLOCK 4
 #define ABD_BLOCK (64 * ABD_WAVES_PER_BLOCK)
 
-// raw sums accumulated on the device; per-chain constants are applied on the host (abd_capi.hip: assemble)
+// raw sums accumulated on the device; per-chain constants are applied on the host (abd_terms.hpp: assemble_terms)
 //   q = od - d s,  s = 1 / (1 + exp(b (a - x))),  h' = q s (1 - s)
 //   d ll / d a = -b (d / sigma^2) h'
 enum {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction counts per kernel of a device-only assembly listing:
-   hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S abdpymc_amd/csrc/abd_capi.hip -o build/abd.s
+   hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S abdpymc_amd/csrc/abd_eval.hip -o build/eval.s
    python tools/isa_stats.py build/abd.s [name filter]
 Used to check that a refactoring leaves a tuned kernel's code unchanged (and to count what a change costs)."""
 import re

@@ -3,7 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
-#include "../../abdpymc_amd/csrc/abd_kernels.hpp"
+#include "../../abdpymc_amd/csrc/abd_device.hpp"
 
 __global__ void k(const double* x, const double* arg, double* r0, double* r1, double* r2, double* ex, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -18,7 +18,7 @@ import pytest
 from abdpymc_amd import synthetic
 from abdpymc_amd.data import TiterData
 from oracle import abd_oracle as O
-from tests.helpers import oracle_cohort_from_synth
+from tests.helpers import oracle_cohort_from_synth, random_sparse_cohort
 
 pytestmark = pytest.mark.gpu
 
@@ -641,3 +641,42 @@ def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch):
     assert np.array_equal(s_a["n_steps"][:, :3], s_host["n_steps"][:, :3])
     np.testing.assert_allclose(t_a[:, :3], t_host[:, :3], rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(s_a["lp"][:, :3], s_host["lp"][:, :3], rtol=1e-9)
+
+
+def test_observation_list_trains_beyond_256_gaps_report_the_oracles_logp(monkeypatch):
+    """Leapfrog trains through the 8-word form of the lane-per-observation kernel (n_gaps = 300, two splits): every recorded
+    draw's `i_raw` / `ab_s_waner` and theta give, in the oracle, the joint logp the sampler reported for that draw (the
+    value its device-side epilogue assembled after the sweep), and the run repeats itself bit for bit."""
+    from abdpymc_amd._native import Context
+
+    G, N, C, n_it = 300, 29, 3, 12
+    splits = (100, 201)
+    coh = random_sparse_cohort(N, G, 1500, 1200, seed=77)
+    monkeypatch.setenv("ABD_SAMPLER_UNIT", "1")
+    monkeypatch.setenv("ABD_SAMPLER_TRAINS", "1")
+
+    def run():
+        ctx = Context(G, N, (coh.s.idx_gap, coh.s.idx_ind, coh.s.log_dilution, coh.s.od),
+                      (coh.n.idx_gap, coh.n.idx_ind, coh.n.log_dilution, coh.n.od), coh.vacs, coh.pcrpos, splits=splits, n_chains=C)
+        assert not ctx.is_dense
+        rng = np.random.default_rng(5)
+        q0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+        for c in range(C):
+            ctx.set_discrete(c, (rng.random((G, N)) < 2.0 / G).astype(np.int8), (rng.random(N) < 0.5).astype(np.int8))
+        smp = ctx.sampler(np.arange(C), q0, tune=8, seed=21)
+        rec = dict(i_raw=np.zeros((C, n_it, G, N), np.int8), ab_s_waner=np.zeros((C, n_it, N), np.int8))
+        th, st = smp.run_record(n_it, 0, **rec)
+        fb = ctx.wait_fallbacks
+        smp.close()
+        ctx.close()
+        return th, st, rec, fb
+
+    th, st, rec, fb = run()
+    th2, st2, rec2, fb2 = run()
+    assert fb == 0 and fb2 == 0
+    assert np.array_equal(th, th2) and np.array_equal(st["lp"], st2["lp"]) and np.array_equal(rec["i_raw"], rec2["i_raw"])
+    assert (st["n_steps"] >= 1).all() and st["n_steps"].max() > 3 and np.isfinite(th).all()
+    for c in range(C):
+        for k in (0, 5, n_it - 1):
+            lp = O.logp_dlogp(th[c, k], rec["i_raw"][c, k], rec["ab_s_waner"][c, k], coh, splits)[0]
+            assert abs(lp - st["lp"][c, k]) <= 1e-9 * abs(lp), (c, k, lp, st["lp"][c, k])

@@ -302,7 +302,7 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
     HIP_TRY(hipMalloc(&d.yx, yx.size() * sizeof(YX<R>)));
     HIP_TRY(hipMemcpy(d.yx, yx.data(), yx.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
     // the split panels of one-chain launches: od alone + one byte per cell coding its log dilution (assays use a handful of
-    // dilutions; lossless: the dictionary holds the doubles as given).  Lane-group-major: element (g, j) at
+    // dilutions; lossless: the dictionary holds the values of the pair panel, i.e. rounded to the storage type).  Lane-group-major: element (g, j) at
     // [((j / 64) * G + g) * 64 + j % 64], so the rows a wave walks -- 64 individuals, gap after gap -- are one contiguous
     // stream (a 64-byte code row is half a cache line: in gap-major order its other half belongs to the neighbouring lane
     // group and was fetched again by that group's wave, 1.29 x the algorithmic bytes at config 5)
@@ -312,7 +312,7 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
     std::vector<uint8_t> code(n_lg * (size_t)G * 64, 0);
     bool fits = true;
     for (size_t k = 0; k < K && fits; ++k) {
-      const double x = o.log_dilution[k];
+      const double x = (double)(R)o.log_dilution[k];  // what the pair panel holds: the value in the storage type
       size_t q = 0;
       while (q < dict.size() && std::memcmp(&dict[q], &x, sizeof x) != 0) ++q;  // bit-wise: -0.0, NaN payloads stay what they are
       if (q == dict.size()) {

@@ -460,3 +460,34 @@ def test_one_chain_launches_read_the_split_panels_and_agree_with_the_pair_panels
             assert_close(lp4[c], g4[c], *ref)
             assert abs(lp1 - lp4[c]) <= 1e-12 * abs(lp1)
         ctx.close()
+
+
+def test_fp32_storage_split_panels_hold_what_the_pair_panels_hold():
+    """fp32 storage with log dilutions that fp32 does not hold exactly (log10 of the assay's dilutions): the one-chain launch
+    (split panels: od + dictionary code) and the batched launch (pair panels) both see the fp32-rounded values, so they
+    agree to rounding with each other and with the oracle on the rounded panels."""
+    sc = synthetic.make_cohort(150, 70, seed=31)
+    coh = oracle_cohort_from_synth(sc)
+    rng = np.random.default_rng(2)
+    dil = np.log10(np.array([100.0, 300.0, 640.0, 2000.0, 5000.0]))
+    coh.s.log_dilution[:] = rng.choice(dil, coh.s.log_dilution.size)
+    coh.n.log_dilution[:] = rng.choice(dil, coh.n.log_dilution.size)
+    ctx = _ctx(coh, (20, 45), n_chains=2, storage="f32")
+    assert ctx.is_dense
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    coh32 = O.Cohort(coh.n_gaps, coh.n_inds, coh.vacs, coh.pcrpos,
+                     O.AntigenObs(coh.s.idx_gap, coh.s.idx_ind, r32(coh.s.log_dilution), r32(coh.s.od)),
+                     O.AntigenObs(coh.n.idx_gap, coh.n.idx_ind, r32(coh.n.log_dilution), r32(coh.n.od)))
+    th = []
+    for c in range(2):
+        theta, i_raw, w = _state(coh, 40 + c)
+        ctx.set_discrete(c, i_raw, w)
+        th.append((theta, i_raw, w))
+    lp_b, g_b = ctx.logp_dlogp_batch(np.arange(2, dtype=np.int32), np.stack([t[0] for t in th]))  # pair panels
+    for c in range(2):
+        lp1, g1 = ctx.logp_dlogp(c, th[c][0])  # split panels
+        lp_ref, g_ref = O.logp_dlogp(th[c][0], th[c][1], th[c][2], coh32, (20, 45))
+        assert_close(lp1, g1, lp_ref, g_ref)
+        assert_close(lp_b[c], g_b[c], lp_ref, g_ref)
+        assert abs(lp1 - lp_b[c]) <= 1e-12 * abs(lp_ref)
+    ctx.close()

@@ -4,6 +4,8 @@
 // (reference abdpymc/abd.py:396-469): the closed-form prior terms + transform Jacobians are evaluated
 // here on the host (17 scalars), the O(G*N) data term on the device (abd_dense.hpp, abd_obs.hpp, abd_sparse.hpp).
 #include "abd_host.hpp"
+
+#include <unordered_map>
 #include "abd_small.hpp"
 
 namespace abdi {
@@ -307,19 +309,25 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
     // stream (a 64-byte code row is half a cache line: in gap-major order its other half belongs to the neighbouring lane
     // group and was fetched again by that group's wave, 1.29 x the algorithmic bytes at config 5)
     std::vector<double> dict;
+    std::unordered_map<uint64_t, uint8_t> code_of;  // bit pattern of a log dilution -> its code
     const size_t n_lg = ((size_t)N + 63) / 64;
     auto cell_of = [&](size_t g, size_t j) { return ((j / 64) * (size_t)G + g) * 64 + j % 64; };
     std::vector<uint8_t> code(n_lg * (size_t)G * 64, 0);
     bool fits = true;
     for (size_t k = 0; k < K && fits; ++k) {
       const double x = (double)(R)o.log_dilution[k];  // what the pair panel holds: the value in the storage type
-      size_t q = 0;
-      while (q < dict.size() && std::memcmp(&dict[q], &x, sizeof x) != 0) ++q;  // bit-wise: -0.0, NaN payloads stay what they are
-      if (q == dict.size()) {
-        if (dict.size() == ABD_XDICT) fits = false;
-        else dict.push_back(x);
+      uint64_t bits;
+      std::memcpy(&bits, &x, sizeof bits);  // bit-wise: -0.0, NaN payloads stay what they are
+      auto it = code_of.find(bits);
+      if (it == code_of.end()) {
+        if (dict.size() == ABD_XDICT) {
+          fits = false;
+          break;
+        }
+        it = code_of.emplace(bits, (uint8_t)dict.size()).first;
+        dict.push_back(x);
       }
-      if (fits) code[cell_of((size_t)o.idx_gap[k], (size_t)o.idx_ind[k])] = (uint8_t)q;
+      code[cell_of((size_t)o.idx_gap[k], (size_t)o.idx_ind[k])] = it->second;
     }
     if (fits) {
       std::vector<R> od(code.size(), (R)0);

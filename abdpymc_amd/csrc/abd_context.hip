@@ -110,6 +110,8 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.ob_c = c->ob_c;
   a.yx_n = c->n.yx;
   a.yx_s = c->s.yx;
+  a.yxi_n = c->n.yxi;
+  a.yxi_s = c->s.yxi;
   a.od_n = c->n.od;
   a.od_s = c->s.od;
   a.xc_n = c->n.xc;
@@ -303,6 +305,13 @@ int upload_antigen(abd_ctx* c, const abd_antigen_obs& o, const SortedObs& so, An
       }
     HIP_TRY(hipMalloc(&d.yx, yx.size() * sizeof(YX<R>)));
     HIP_TRY(hipMemcpy(d.yx, yx.data(), yx.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
+    {  // the individual-major copy the sweep kernels read: element (g, j) at [j * G + g]
+      std::vector<YX<R>> yxi((size_t)G * N);
+      for (int j = 0; j < N; ++j)
+        for (int g = 0; g < G; ++g) yxi[(size_t)j * G + g] = yx[(size_t)g * N + j];
+      HIP_TRY(hipMalloc(&d.yxi, yxi.size() * sizeof(YX<R>)));
+      HIP_TRY(hipMemcpy(d.yxi, yxi.data(), yxi.size() * sizeof(YX<R>), hipMemcpyHostToDevice));
+    }
     // the split panels of one-chain launches: od alone + one byte per cell coding its log dilution (assays use a handful of
     // dilutions; lossless: the dictionary holds the values of the pair panel, i.e. rounded to the storage type).  Lane-group-major: element (g, j) at
     // [((j / 64) * G + g) * 64 + j % 64], so the rows a wave walks -- 64 individuals, gap after gap -- are one contiguous
@@ -390,6 +399,7 @@ void free_ctx(abd_ctx* c) {
     if (a->yx) (void)hipFree(a->yx);
     if (a->od) (void)hipFree(a->od);
     if (a->xc) (void)hipFree(a->xc);
+    if (a->yxi) (void)hipFree(a->yxi);
     if (a->dict) (void)hipFree(a->dict);
   }
   if (c->vw) (void)hipFree(c->vw);

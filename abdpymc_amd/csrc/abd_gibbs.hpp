@@ -236,8 +236,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
         Rw[t] = uniform_word(rw, (int64_t)t * N + j);
         if (DENSE) {
           const int g = min(t * 64 + lane, G - 1);
-          dn[t] = reinterpret_cast<const YX<R>*>(a.yx_n)[(int64_t)g * N + j];  // one strided gather per sweep
-          ds[t] = reinterpret_cast<const YX<R>*>(a.yx_s)[(int64_t)g * N + j];
+          dn[t] = reinterpret_cast<const YX<R>*>(a.yxi_n)[(int64_t)j * G + g];  // the individual's gap axis: contiguous
+          ds[t] = reinterpret_cast<const YX<R>*>(a.yxi_s)[(int64_t)j * G + g];
         }
       }
     }

@@ -346,7 +346,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
   for (;;) {
-    // ---- next individual of this chain: one queue per chain, so that the waves stay busy to the end ----
+    // ---- next individual of this chain: one queue per chain, one individual per pop, so that the waves stay busy to the
+    // end (guided chunks of up to 8 were measured: the pops themselves got cheaper -- a sweep that proposes nothing 0.54 ->
+    // 0.28 ms -- but the coarser hand-out cost more at the end of a real sweep: 0.91 -> 0.95 ms converged, 2.26 -> 2.45 ms random)
     int j = 0;
     if (lane == 0) j = (int)atomicAdd(ga.work + c, 1u);
     j = __builtin_amdgcn_readfirstlane(j);
@@ -362,9 +364,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
         Rw[t] = uniform_word(rw, (int64_t)t * N + j);
         const int g = t * 64 + lane;
-        if (g < G) {  // one strided gather per sweep
-          dataN[g] = reinterpret_cast<const YX<R>*>(a.yx_n)[(int64_t)g * N + j];
-          dataS[g] = reinterpret_cast<const YX<R>*>(a.yx_s)[(int64_t)g * N + j];
+        if (g < G) {  // the individual's gap axis from the individual-major copy: contiguous, 1 KB per wave load
+          dataN[g] = reinterpret_cast<const YX<R>*>(a.yxi_n)[(int64_t)j * G + g];
+          dataS[g] = reinterpret_cast<const YX<R>*>(a.yxi_s)[(int64_t)j * G + g];
         }
       }
     }

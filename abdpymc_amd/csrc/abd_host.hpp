@@ -78,6 +78,7 @@ struct AntigenDev {
   int32_t* ptr = nullptr;  // sparse: (N+1)
   int32_t* j = nullptr;    // sparse: individual per obs
   void* yx = nullptr;      // dense: [G][N] of {od, log_dilution}
+  void* yxi = nullptr;     // dense: the same pairs individual-major, [N][G] (the sweep kernels' reads)
   // dense, when the antigen has <= 256 distinct log dilutions: the split panels of one-chain launches (abd_dense.hpp: XC)
   void* od = nullptr;        // [lane group][G][64] od in the storage type (lane-group-major)
   uint8_t* xc = nullptr;     // [lane group][G][64] code of the cell's log dilution

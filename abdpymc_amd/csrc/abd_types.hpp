@@ -109,6 +109,10 @@ struct EvalArgs {
   // dense panels, gap-major [G][N] of {od, log_dilution}
   const void* yx_n;
   const void* yx_s;
+  // ... and individual-major [N][G] copies for the sweep kernels, which read ONE individual's whole gap axis at a time (3.2 KB
+  // contiguous per antigen at 200 gaps, fp64; from the gap-major panel the same read touches 200 cache lines)
+  const void* yxi_n;
+  const void* yxi_s;
   // the same panels split for launches that evaluate one chain (abd_dense.hpp: XC): od [lane group][G][64] in the storage type, a
   // one-byte code per cell into the antigen's dictionary of distinct log dilutions (nullptr: more than 256 distinct values)
   const void* od_n;
@@ -195,7 +199,9 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
   return o;
 }
 
+#ifndef ABD_TRANSIT_P_U32  // (a diagnostic build may set it to 0: a sweep that proposes nothing measures the per-individual set-up)
 #define ABD_TRANSIT_P_U32 3435973836u  // floor(0.8 * 2^32): propose iff word 1 < this   (transit_p = 0.8)
+#endif
 // per-wave LDS of abd_gibbs_kernel: sort keys u32[G+1] + order u16[G+1] + transit u8[G+1] + log u f64[G+1], each padded to 16 bytes
 __host__ __device__ inline size_t abd_gibbs_pad16(size_t b) { return (b + 15) / 16 * 16; }
 __host__ __device__ inline size_t abd_gibbs_wave_lds(int G) {

@@ -70,6 +70,7 @@ class _Record(C.Structure):
     _fields_ = [
         ("capacity", C.c_int64),
         ("first", C.c_int64),
+        ("thin", C.c_int64),
         ("i_raw", C.POINTER(C.c_int8)),
         ("ab_s_waner", C.POINTER(C.c_int8)),
         ("i", C.POINTER(C.c_int8)),
@@ -582,12 +583,15 @@ class NativeSampler:
         _check(self._lib, self._lib.abd_sampler_run(self._h, int(n_iter), _ptr(theta, C.c_double), _ptr(stats, C.c_double)))
         return theta, {name: stats[:, :, k].copy() for k, name in enumerate(STAT_NAMES)}
 
-    def run_record(self, n_iter: int, first: int, i_raw=None, ab_s_waner=None, i=None, ab_n_mu=None, ab_s_mu=None):
+    def run_record(self, n_iter: int, first: int, i_raw=None, ab_s_waner=None, i=None, ab_n_mu=None, ab_s_mu=None, thin: int = 1):
         """
         run() that also writes every iteration's discrete state / Deterministics of every chain into the given
         C-contiguous arrays of shape (n, capacity, G, N) (int8 for i_raw and i, float64 for the two mu) and
-        (n, capacity, N) int8 for ab_s_waner, at draws first .. first + n_iter - 1.
+        (n, capacity, N) int8 for ab_s_waner, at draws first .. first + n_iter - 1.  thin = K > 1: only iterations
+        0, K, 2K, ... of the call are written, at draws first, first + 1, ... (ceil(n_iter / K) of them).
         """
+        if thin < 1:
+            raise ValueError(f"thin must be >= 1, got {thin}")
         G, N = self._ctx.n_gaps, self._ctx.n_inds
         rec = _Record()
         cap = None
@@ -602,7 +606,7 @@ class NativeSampler:
                 raise ValueError("record arrays differ in capacity")
             cap = arr.shape[1]
             setattr(rec, name, _tptr(arr, C.c_int8 if dt == np.int8 else C.c_double))
-        rec.capacity, rec.first = int(cap or 0), int(first)
+        rec.capacity, rec.first, rec.thin = int(cap or 0), int(first), int(thin)
         theta = np.empty((self.n, n_iter, N_THETA))
         stats = np.empty((self.n, n_iter, N_STATS))
         self._ctx._bump(self._chains)

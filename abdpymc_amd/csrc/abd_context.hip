@@ -580,6 +580,7 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
     return rc;
   }
   c->xc_ok = c->dense && c->s.od && c->n.od;
+  c->xc_max_cb = tune_int("ABD_XC_MAX_CB", c->xc_max_cb);
   const size_t cells = (size_t)G * N;
   const size_t words = (size_t)c->nt * N;
   {
@@ -805,7 +806,8 @@ int64_t abd_algorithmic_bytes(abd_ctx* c, int32_t n_chains) {
   // indicator panels are bit-packed in 64-gap words: vacs + pcrpos + one i_raw per chain, plus the waner bytes
   const int64_t bits = (int64_t)c->nt * c->N * 8 * (2 + n_chains) + (int64_t)n_chains * c->N;
   // one chain per launch reads the split panels (od + a one-byte dilution code per cell and antigen) where they exist
-  if (c->dense && c->xc_ok && (n_chains & 1)) return cells * 2 * (R + 1) + bits;
+  const int cpw = n_chains % 4 == 0 ? 4 : (n_chains % 2 == 0 ? 2 : 1);  // abd_eval.hip: pick_cpw
+  if (c->dense && c->xc_ok && cpw <= c->xc_max_cb) return cells * 2 * (R + 1) + bits;
   if (c->dense) return cells * 4 * R + bits;
   return (c->s.K + c->n.K) * (2 * R + 2) + 2 * (int64_t)(c->N + 1) * 4 + bits;
 }

@@ -92,8 +92,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const void* base, int6
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off, 0, -1, 0x00020000);
 }
 // (built outside divergent code, or every load through a descriptor becomes a waterfall loop)
-template <typename R, bool XC>
-__device__ __forceinline__ RowDesc<XC> row_desc(const EvalArgs& a, int antigen, int lg, int g0) {
+template <typename R, bool XC, typename ARGS>
+__device__ __forceinline__ RowDesc<XC> row_desc(const ARGS& a, int antigen, int lg, int g0) {
   RowDesc<XC> d;
   if constexpr (XC) {  // lane-group-major: [lane group][gap][64]
     const int64_t cell0 = ((int64_t)lg * a.G + g0) * 64;
@@ -245,8 +245,8 @@ struct PieceLoads {
   int wj;                           // ab_s_waner of the lane's individual
 };
 
-template <typename R, bool XC>
-__device__ __forceinline__ void piece_issue_loads(const EvalArgs& a, const RowDesc<XC>& rs_n, const RowDesc<XC>& rs_s,
+template <typename R, bool XC, typename ARGS>
+__device__ __forceinline__ void piece_issue_loads(const ARGS& a, const RowDesc<XC>& rs_n, const RowDesc<XC>& rs_s,
                                                   const uint32_t* ibase, const uint32_t* vbase, const int8_t* waner, int lane, int j,
                                                   int g0, int g1, PieceLoads<R, XC>& pl) {
   const int N = a.N;
@@ -357,8 +357,8 @@ __device__ __forceinline__ void dense_start_state(uint32_t (&wi)[ABD_SW], uint32
 }
 
 // Walk gaps [g0, g1) of lane group lg: recurrence form (abd.py:288) + likelihood terms into acc.
-template <typename R, bool GRAD, bool XC>
-__device__ __forceinline__ void dense_walk(const EvalArgs& a, const DenseChain& k, const RowDesc<XC>& rs_n,
+template <typename R, bool GRAD, bool XC, typename ARGS>
+__device__ __forceinline__ void dense_walk(const ARGS& a, const DenseChain& k, const RowDesc<XC>& rs_n,
                                            const RowDesc<XC>& rs_s, const double* dict_n, const double* dict_s,
                                            const uint32_t* ibase, const uint32_t* vbase,
                                            uint32_t j2, PieceLoads<R, XC>& pl, int lane, int g0, int g1, bool wj, double tn, double dn, double ts,
@@ -558,20 +558,36 @@ __device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, in
 }
 
 // dynamic LDS of the kernel: [CB][2][G+1] power tables, block reduction, 2^(j/1024) table (and at least the scratch of the
-// fused fixed-order sum)
-__host__ __device__ inline size_t abd_dense_lds(int G, int cb, bool xc = false) {
+// fused fixed-order sum; a train launch's last workgroup also keeps the sums of its chains there: abd_train.hpp)
+#define ABD_TRAIN_SM 64  // doubles of LDS per chain of a train launch's last workgroup: 16 sums, 17 shares of logp
+__host__ __device__ inline size_t abd_dense_lds(int G, int cb, bool xc = false, bool train = false) {
   const size_t need = (size_t)cb * 2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
                       (size_t)ABD_EXP2_TAB * sizeof(double) + (xc ? (size_t)2 * ABD_XDICT * sizeof(double) : 0);
-  const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
+  const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double) + (train ? (size_t)ABD_TRAIN_CB * ABD_TRAIN_SM * sizeof(double) : 0);
   return need > fin ? need : fin;
 }
 
-template <typename R, int CB, bool GRAD, bool XC>
-#ifndef ABD_DENSE_MINW
-#define ABD_DENSE_MINW 4
-#endif
-__global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
+template <typename ARGS>
+struct is_train_args {
+  static constexpr bool value = false;
+};
+template <>
+struct is_train_args<DenseTrainArgs> {
+  static constexpr bool value = true;
+};
+
+// (abd_train.hpp)
+__device__ __forceinline__ void train_service(const DenseTrainArgs& a, int wave, int lane);
+__device__ __forceinline__ void train_step(const DenseTrainArgs& a, const TrainChainArgs& tc, double* sm, int lane);
+
+// The kernel's body for both of its entry points: abd_dense_kernel (EvalArgs: the chains' constants arrive in the kernel
+// arguments, the sums go back to the host) and abd_train_kernel (DenseTrainArgs: a leapfrog-train launch -- the constants
+// of a chain are those of the point its TrainChain holds, and the launch's last workgroup runs the chains' state machines).
+template <typename R, int CB, bool GRAD, bool XC, typename ARGS>
+__device__ __forceinline__ void dense_body(const ARGS& a) {
+  constexpr bool TRAINK = is_train_args<ARGS>::value;
   static_assert(CB * ABD_NOUT <= 64, "the own-sum hand-off needs every partial row of the workgroup stored by wave 0");
+  static_assert(!TRAINK || (GRAD && CB <= ABD_TRAIN_CB), "a train launch evaluates gradients for at most ABD_TRAIN_CB chains");
   extern __shared__ __align__(16) unsigned char smem[];
   const int G = a.G, N = a.N;
   const int tstride = G + 1;
@@ -580,7 +596,6 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   double* tab_e2 = red + ABD_WAVES_PER_BLOCK * ABD_NOUT;             // [ABD_EXP2_TAB] 2^(j/1024)
   double* dict_n = tab_e2 + ABD_EXP2_TAB;                            // XC: [ABD_XDICT] distinct log dilutions, N antigen ...
   double* dict_s = dict_n + ABD_XDICT;                               // ... and S antigen
-  static_assert(!XC || CB == 1, "the split panels serve launches that evaluate one chain");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -589,40 +604,64 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   const int c = wave % CB;                        // this wave's chain within the block's group
   const int sub = wave / CB;
   const int cbase = blockIdx.y * CB;
-  ChainPar p = a.ch[cbase + c];
-  constexpr bool TRAIN = CB == 1 && GRAD;  // leapfrog trains: one chain per launch (abd_types.hpp: TrainArgs)
-  if (TRAIN && a.train.enabled && a.train.use_slot >= 0) {
-    // the point was left in device memory by the launch before this one on the stream
-    const double* tr = a.train.slots[a.train.use_slot].tr;
-    p.perm_n = tr[1];
-    p.temp_n = tr[2];
-    p.rho_n = tr[3];
-    p.init_n = tr[4];
-    p.perm_s = tr[5];
-    p.rho_s = tr[6];
-    p.init_s = tr[10];
-    p.b_n = tr[11];
-    p.d_n = tr[12];
-    p.b_s = tr[14];
-    p.d_s = tr[15];
-    if (a.train.fwd_rec && blockIdx.x == 0 && wave == ABD_WAVES_PER_BLOCK - 1) train_forward_record(a.train, lane);
+  // a train launch may carry one more workgroup than it has ranges, dispatched first: the SERVICE workgroup passes the
+  // records of the unit's previous steps on to the host (a PCIe round trip behind a system-scope fence, ~3 us -- done by a
+  // workgroup that also walks a range, that range would end ~3 us after all the others and the whole launch with it)
+  int service = 0;
+  if constexpr (TRAINK) {
+    service = a.service;
+    if (service && blockIdx.x == 0) {
+      train_service(a, wave, lane);
+      return;
+    }
+  }
+  ChainPar p;
+  bool chain_on = true;  // (wave-uniform) a train launch leaves the chains of its unit alone that do not step in it
+  if constexpr (TRAINK) {
+    const TrainChainArgs& tc = a.tc[c];
+    chain_on = tc.action == ABD_TR_STEP;
+    p.rw = nullptr;
+    p.waner = tc.waner;
+    p.iw = tc.iw;
+    p.cnt = tc.cnt;
+    p.perm_n = p.temp_n = p.rho_n = p.init_n = p.perm_s = p.rho_s = p.init_s = p.b_n = p.d_n = p.b_s = p.d_s = 0.0;
+    if (chain_on) {
+      // the point was left in device memory by the launch before this one on the stream (abd_terms.hpp: Transformed)
+      const double* tr = tc.st->pt[tc.use_slot].tr;
+      p.perm_n = tr[1];
+      p.temp_n = tr[2];
+      p.rho_n = tr[3];
+      p.init_n = tr[4];
+      p.perm_s = tr[5];
+      p.rho_s = tr[6];
+      p.init_s = tr[10];
+      p.b_n = tr[11];
+      p.d_n = tr[12];
+      p.b_s = tr[14];
+      p.d_s = tr[15];
+    }
+  } else {
+    p = a.ch[cbase + c];
   }
 
   // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2: give every XCD one contiguous
   // eighth of the plane, so that the neighbouring ranges that re-read one lane group's packed words (and the rows
   // shared at range borders) find them in their own L2 instead of fetching them again.
-  // blk = this workgroup's position in range order (a bijection of blockIdx.x for any grid size).
+  // blk = this workgroup's position in range order (a bijection of the workgroup ids for any grid size).
   ABD_STAMP(0);
-  const int nblk = (int)gridDim.x;
-  const int xcd = (int)blockIdx.x % 8, q8 = nblk / 8, rem8 = nblk % 8;
-  const int blk = a.xcd_remap ? xcd * q8 + min(xcd, rem8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int nblk = (int)gridDim.x - service;
+  const int bid = (int)blockIdx.x - service;
+  const int xcd = bid % 8, q8 = nblk / 8, rem8 = nblk % 8;
+  const int blk = a.xcd_remap ? xcd * q8 + min(xcd, rem8) + bid / 8 : bid;
 
   // the workgroups that own the first ranges of grid row 0 first sum the previous launch's partials (EvalArgs::prev_*)
-  const int n_fin = blockIdx.y == 0 ? a.prev_n_chains : 0;
-  if (blk < n_fin) {
-    finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blk * a.prev_blocks * ABD_NOUT, a.prev_blocks,
-                   a.prev_out + (int64_t)blk * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.prev_tag);
-    __syncthreads();  // the scratch becomes the power tables
+  if constexpr (!TRAINK) {
+    const int n_fin = blockIdx.y == 0 ? a.prev_n_chains : 0;
+    if (blk < n_fin) {
+      finalize_chain<ABD_BLOCK>(a.prev_partials + (int64_t)blk * a.prev_blocks * ABD_NOUT, a.prev_blocks,
+                     a.prev_out + (int64_t)blk * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.prev_tag);
+      __syncthreads();  // the scratch becomes the power tables
+    }
   }
 
   // the 2^(j/1024) table is requested first and stored last: its loads are in flight while everything else is set up
@@ -650,6 +689,7 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   };
   int lg, g0, rows_left;
   range_of(blk * NSUB + sub, lg, g0, rows_left);
+  if (TRAINK && !chain_on) rows_left = 0;
   // power-table entries this workgroup reads: up to the largest start gap of its ranges
   int n_entries = rows_left > 0 ? g0 + 1 : 0;
 #pragma unroll
@@ -659,6 +699,7 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
       range_of(blk * NSUB + s, o_lg, o_g0, o_rows);
       n_entries = max(n_entries, o_rows > 0 ? o_g0 + 1 : 0);
     }
+  if (TRAINK && !chain_on) n_entries = 0;
   ABD_STAMP(1);
 #ifdef ABD_STAMPS
   if (a.stamps && wave == 0 && lane == 0 && blockIdx.y == 0) a.stamps[(int64_t)blockIdx.x * 16 + 9] = (unsigned long long)g0;  // (diagnostic)
@@ -680,7 +721,7 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   // sum(i_raw), sum(ab_s_waner) of the chain: kept with the slot's discrete state (Bernoulli(i_raw | p) is on the RAW
   // matrix, abd.py:427; Q2); the first range of a chain carries them into the sums
   long long n1 = 0, m1 = 0;  // (kept as integers in scalar registers until the walk is over)
-  if (blk == 0 && sub == 0) {
+  if (blk == 0 && sub == 0 && chain_on) {
     n1 = p.cnt[0];
     m1 = p.cnt[1];
   }
@@ -760,51 +801,89 @@ __global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(co
   const double tot = wave_reduce16(acc, lane);
   if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
   __syncthreads();
+  bool own_sum = TRAINK;  // does the launch sum its own partial rows?
+  if constexpr (!TRAINK) own_sum = a.fin_count != nullptr;
   if (tid < CB * ABD_NOUT) {
     const int cc = tid / ABD_NOUT, k = tid % ABD_NOUT;
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < NSUB; ++w) v += red[(w * CB + cc) * ABD_NOUT + k];  // waves w*CB + cc hold chain cc
-    double* dst = a.partials + ((int64_t)(cbase + cc) * gridDim.x + blk) * ABD_NOUT + k;  // rows in range order
-    if (a.fin_count)
+    double* dst = a.partials + ((int64_t)(cbase + cc) * nblk + blk) * ABD_NOUT + k;  // rows in range order
+    if (own_sum)
       __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another workgroup of THIS launch
     else
       *dst = v;
   }
   ABD_STAMP(8);
-  if (!a.fin_count) return;
+  if (!own_sum) return;
 
-  // ---- own fixed-order sum: the workgroup that counts in last for a chain sums that chain's partial rows itself instead of
-  // a second launch.  Hand-off (MI355X guide, "valid forms"): every partial row of this workgroup was stored write-through
+  // ---- own fixed-order sum: the workgroup that counts in last sums the partial rows itself instead of a second launch.
+  // Hand-off (MI355X guide, "valid forms"): every partial row of this workgroup was stored write-through
   // (sc1) by wave 0 (CB x 16 <= 64 lanes), wave 0 drains its stores (s_waitcnt vmcnt(0)) and then one lane per chain counts
   // in with a returning agent-scope add; the workgroup whose add came last re-reads the rows with sc1 loads behind a barrier
   int* flag = reinterpret_cast<int*>(red);  // the block reduction is done with: [CB] flags
   __syncthreads();
-  if (wave == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane < CB) {
-      const unsigned int old = __hip_atomic_fetch_add(a.fin_count + cbase + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[lane] = old + 1u == gridDim.x ? 1 : 0;
+  if constexpr (TRAINK) {
+    // one counter for the launch: its last workgroup sums the rows of every chain that stepped and then runs the chains'
+    // state machines, wave k chain k's (abd_train.hpp)
+    if (wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(a.fin_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = old + 1u == (unsigned int)nblk ? 1 : 0;
+      }
     }
-  }
-  __syncthreads();
-  bool last[CB];  // workgroup-uniform; read before the sum's scratch may overwrite the flags
+    __syncthreads();
+    const bool last = flag[0] != 0;
+    __syncthreads();
+    if (!last) return;
+    double* sm = reinterpret_cast<double*>(smem);
+    double* sm_chain = sm + ABD_FIN_PARTS * ABD_NOUT;  // [CB][ABD_TRAIN_SM]
 #pragma unroll
-  for (int cc = 0; cc < CB; ++cc) last[cc] = flag[cc] != 0;
-  __syncthreads();
+    for (int cc = 0; cc < CB; ++cc) {
+      if (a.tc[cc].action == ABD_TR_STEP) {  // (workgroup-uniform)
+        sum_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)cc * nblk * ABD_NOUT, nblk, sm, tid);
+        if (tid < ABD_NOUT) sm_chain[cc * ABD_TRAIN_SM + tid] = sm[tid];
+        __syncthreads();
+      }
+    }
+    if (wave < CB && a.tc[wave].action != ABD_TR_SKIP) train_step(a, a.tc[wave], sm_chain + wave * ABD_TRAIN_SM, lane);
+    if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane < CB) {
+        const unsigned int old = __hip_atomic_fetch_add(a.fin_count + cbase + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[lane] = old + 1u == gridDim.x ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    bool last[CB];  // workgroup-uniform; read before the sum's scratch may overwrite the flags
 #pragma unroll
-  for (int cc = 0; cc < CB; ++cc) {
-    if (last[cc]) {
-      if (TRAIN && a.train.enabled) {
-        sum_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
-                                      reinterpret_cast<double*>(smem), tid);
-        if (wave == 0) train_epilogue(a, reinterpret_cast<double*>(smem), lane);
-      } else {
+    for (int cc = 0; cc < CB; ++cc) last[cc] = flag[cc] != 0;
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
+      if (last[cc]) {
         finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
                                            a.fin_out + (int64_t)(cbase + cc) * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.fin_tag);
+        if (tid == 0) __hip_atomic_store(a.fin_count + cbase + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
       }
-      if (tid == 0) __hip_atomic_store(a.fin_count + cbase + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
     }
   }
+}
+
+template <typename R, int CB, bool GRAD, bool XC>
+#ifndef ABD_DENSE_MINW
+#define ABD_DENSE_MINW 4
+#endif
+__global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_dense_kernel(const EvalArgs a) {  // 4 waves per SIMD: <= 128 VGPRs
+  dense_body<R, CB, GRAD, XC, EvalArgs>(a);
+}
+
+// a leapfrog-train launch of a unit of CB chains (abd_train.hpp; abd_sampler.hip)
+template <typename R, int CB, bool XC>
+__global__ __launch_bounds__(ABD_BLOCK, ABD_DENSE_MINW) void abd_train_kernel(const DenseTrainArgs a) {
+  dense_body<R, CB, true, XC, DenseTrainArgs>(a);
 }

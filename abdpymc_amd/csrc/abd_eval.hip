@@ -2,6 +2,7 @@
 // the pipes (HIP streams) stream-ordered launches rotate over, completion tags in mapped host memory, device timing.
 #include "abd_host.hpp"
 #include "abd_eval_kernels.hpp"
+#include "abd_train.hpp"
 
 namespace abdi {
 
@@ -26,17 +27,17 @@ hipError_t launch_k(K kernel, dim3 grid, size_t lds, hipStream_t st, const EvalA
 }
 
 template <typename R, int C>
-hipError_t launch_dense_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a) {
+hipError_t launch_dense_g(bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a, bool xc) {
+  if (xc)  // split panels: R + 1 instead of 2 R bytes per cell and antigen
+    return grad ? launch_k(abd_dense_kernel<R, C, true, true>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, C, false, true>, grid, lds, st, a);
   return grad ? launch_k(abd_dense_kernel<R, C, true, false>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, C, false, false>, grid, lds, st, a);
 }
 template <typename R>
 hipError_t launch_dense(int C, bool grad, dim3 grid, size_t lds, hipStream_t st, const EvalArgs& a, bool xc) {
-  if (xc && C == 1)  // one chain per launch and split panels available: R + 1 instead of 2 R bytes per cell and antigen
-    return grad ? launch_k(abd_dense_kernel<R, 1, true, true>, grid, lds, st, a) : launch_k(abd_dense_kernel<R, 1, false, true>, grid, lds, st, a);
   switch (C) {
-    case 4: return launch_dense_g<R, 4>(grad, grid, lds, st, a);
-    case 2: return launch_dense_g<R, 2>(grad, grid, lds, st, a);
-    default: return launch_dense_g<R, 1>(grad, grid, lds, st, a);
+    case 4: return launch_dense_g<R, 4>(grad, grid, lds, st, a, xc);
+    case 2: return launch_dense_g<R, 2>(grad, grid, lds, st, a, xc);
+    default: return launch_dense_g<R, 1>(grad, grid, lds, st, a, xc);
   }
 }
 template <typename R, int C>
@@ -62,6 +63,9 @@ hipError_t launch_obs(bool grad, dim3 grid, size_t lds, hipStream_t st, const Ev
   return grad ? launch_k(abd_obs_kernel<R, true, ABD_MAXT>, grid, lds, st, a) : launch_k(abd_obs_kernel<R, false, ABD_MAXT>, grid, lds, st, a);
 }
 
+// does a dense launch with cpw chains per workgroup read the split panels (od + one-byte dilution code) or the pair panels?
+bool dense_xc(const abd_ctx* c, int cpw) { return c->xc_ok && cpw <= c->xc_max_cb; }
+
 int pick_cpw(const abd_ctx* c, int n) {
   const int forced = c->cpw_forced;
   if (forced == 1 || forced == 2 || forced == 4) {
@@ -76,7 +80,7 @@ int pick_cpw(const abd_ctx* c, int n) {
 // gap rows), capped so a slot has at least kMinRows rows
 // share: 0 = the launch has the chip to itself, 1 = it is one of n_pipes stream-ordered launches in flight,
 // 2 = it is one of the native sampler's chain groups in flight (c->group_blocks: the chip divided by their number)
-int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
+int dense_blocks(const abd_ctx* c, int cpw, int share, int grid_rows) {
   const int nsub = ABD_WAVES_PER_BLOCK / cpw;
   const int64_t rows = (int64_t)c->n_lg * c->G;
   const int64_t cap = std::max<int64_t>(1, rows / ((int64_t)kMinRows * nsub));
@@ -91,9 +95,10 @@ int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1) {
 // one range per workgroup (nsub == 1) the first ABD_MAX_BATCH ranges -- the workgroups that may carry the fused
 // fixed-order sum of an earlier launch -- are fin_rows shorter and the others share the difference.  The kernel works its
 // range out from these five numbers (abd_types.hpp: EvalArgs::rg_*).
-void range_split(const abd_ctx* c, int blocks, int nsub, EvalArgs& a) {
+template <typename ARGS>
+void range_split(const abd_ctx* c, int blocks, int nsub, ARGS& a, bool fused_sums = true) {
   const int64_t rows_total = (int64_t)c->n_lg * c->G, n_ranges = (int64_t)blocks * nsub;
-  const int64_t n_short = nsub == 1 ? std::min<int64_t>(ABD_MAX_BATCH, n_ranges) : 0;
+  const int64_t n_short = (nsub == 1 && fused_sums) ? std::min<int64_t>(ABD_MAX_BATCH, n_ranges) : 0;
   const int64_t e_fin = (nsub == 1 && (rows_total + n_short * c->fin_rows) / n_ranges >= 2 * c->fin_rows) ? c->fin_rows : 0;
   const int64_t virt = rows_total + n_short * e_fin;
   a.rg_base = (int32_t)(virt / n_ranges);
@@ -169,7 +174,7 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     // the last launch of a batch of stream-ordered steps ends alone on the chip: it gets the grid of a launch that has the
     // chip to itself (one wave per SIMD issues at half the rate; a K = 20 region 376 -> 373 us; a longer tail did not pay)
     blocks = dense_blocks(c, cpw, force_pipe >= 0 ? 2 : (rotate && c->steps_behind != 0 ? 1 : 0), n / cpw);
-    lds = abd_dense_lds(c->G, cpw, cpw == 1 && c->xc_ok);
+    lds = abd_dense_lds(c->G, cpw, dense_xc(c, cpw));
   } else {
     blocks = c->blocks_x;
     lds = table_lds_bytes(c->G, cpw, ABD_WAVES_PER_BLOCK * cpw);
@@ -247,8 +252,8 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     le = c->storage == ABD_STORE_F32 ? launch_obs<float>(grad, grid, lds, pp.st, a)
                                      : launch_obs<double>(grad, grid, lds, pp.st, a);
   else if (c->dense)
-    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, pp.st, a, c->xc_ok)
-                                     : launch_dense<double>(cpw, grad, grid, lds, pp.st, a, c->xc_ok);
+    le = c->storage == ABD_STORE_F32 ? launch_dense<float>(cpw, grad, grid, lds, pp.st, a, dense_xc(c, cpw))
+                                     : launch_dense<double>(cpw, grad, grid, lds, pp.st, a, dense_xc(c, cpw));
   else
     le = c->storage == ABD_STORE_F32 ? launch_sparse<float>(cpw, grad, grid, lds, pp.st, a)
                                      : launch_sparse<double>(cpw, grad, grid, lds, pp.st, a);
@@ -380,6 +385,95 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
 int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms, double* seqp) {
   const int32_t ch = chain;
   return enqueue_group(c, 1, &ch, nullptr, true, c->d_out + (size_t)kSyncSlot * c->n_slots * ABD_NOUT, false, pi, &first_terms, seqp, t);
+}
+
+// ---- leapfrog-train launches of dense cohorts (abd_train.hpp; abd_sampler.hip) ----
+template <typename R, int CB>
+hipError_t launch_train_cb(bool xc, dim3 grid, size_t lds, hipStream_t st, const DenseTrainArgs& a) {
+  auto go = [&](auto kernel) -> hipError_t {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(ABD_BLOCK), lds, st, a);
+    return hipGetLastError();
+  };
+  return xc ? go(abd_train_kernel<R, CB, true>) : go(abd_train_kernel<R, CB, false>);
+}
+template <typename R>
+hipError_t launch_train(int cb, bool xc, dim3 grid, size_t lds, hipStream_t st, const DenseTrainArgs& a) {
+  switch (cb) {
+    case 4: return launch_train_cb<R, 4>(xc, grid, lds, st, a);
+    case 2: return launch_train_cb<R, 2>(xc, grid, lds, st, a);
+    default: return launch_train_cb<R, 1>(xc, grid, lds, st, a);
+  }
+}
+
+// Queue one launch of a train unit of cb (1, 2 or 4) chains on pipe pi: a->tc[0 .. cb) filled by the caller, everything
+// else here.  `blocks`: workgroups with a range (the unit's fixed shape: its chains' numbers depend on nothing else).
+int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* a) {
+  if (!c->dense) return fail(ABD_ERR_STATE, "internal: dense train launch on a cohort kept as observation lists");
+  if (cb != 1 && cb != 2 && cb != 4) return fail(ABD_ERR_STATE, "internal: train unit of %d chains", cb);
+  bool any_step = false, any_fwd = false;
+  for (int k = 0; k < cb; ++k) {
+    TrainChainArgs& tc = a->tc[k];
+    if (tc.action != ABD_TR_SKIP || tc.fwd_slot >= 0) {
+      if (!tc.st || !tc.ring || !tc.iw || !tc.cnt || !tc.waner || (tc.action == ABD_TR_BEGIN && !tc.begin))
+        return fail(ABD_ERR_STATE, "internal: train launch with a NULL pointer for chain %d of the unit", k);
+      if ((tc.action == ABD_TR_STEP && (tc.use_slot | 1) != 1) || tc.fwd_slot > 1)
+        return fail(ABD_ERR_STATE, "internal: train launch with slot %d / %d for chain %d of the unit", tc.use_slot, tc.fwd_slot, k);
+    }
+    any_step |= tc.action == ABD_TR_STEP;
+    any_fwd |= tc.fwd_slot >= 0;
+  }
+  for (int k = cb; k < ABD_TRAIN_CB; ++k) {
+    std::memset(&a->tc[k], 0, sizeof a->tc[k]);
+    a->tc[k].fwd_slot = -1;
+  }
+  if (!any_step) blocks = 1;  // nothing to walk: one workgroup runs the state machines (new transitions)
+  if (blocks < 1 || blocks > c->blocks_max) return fail(ABD_ERR_STATE, "internal: train grid %d outside [1, %d]", blocks, c->blocks_max);
+  const bool xc = c->xc_ok;
+  a->yx_n = c->n.yx;
+  a->yx_s = c->s.yx;
+  a->od_n = c->n.od;
+  a->od_s = c->s.od;
+  a->xc_n = c->n.xc;
+  a->xc_s = c->s.xc;
+  a->dict_n = c->n.dict;
+  a->dict_s = c->s.dict;
+  a->n_dict_n = c->n.n_dict;
+  a->n_dict_s = c->s.n_dict;
+  a->vw = c->vw;
+  a->exp2_tab = c->exp2_tab;
+  abd_ctx::Pipe& pp = c->pipe[pi];
+  if (pp.on)
+    if (int frc = flush_pipe(c, pi)) return frc;  // (a pending fixed-order sum of an earlier plain launch on this stream)
+  if (pi > 0) pp.busy = true;
+  a->partials = pp.partials[0];
+  a->fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
+  a->prior_const = c->prior_const;
+  a->xcd_remap = c->xcd_remap ? 1 : 0;
+  a->service = any_fwd ? 1 : 0;
+  a->G = c->G;
+  a->N = c->N;
+  a->n_lg = c->n_lg;
+  a->K_n = (int32_t)c->n.K;
+  a->K_s = (int32_t)c->s.K;
+#ifdef ABD_STAMPS
+  a->stamps = nullptr;
+#endif
+  range_split(c, blocks, ABD_WAVES_PER_BLOCK / cb, *a, false);
+  const size_t lds = abd_dense_lds(c->G, cb, xc, true);
+  dim3 grid(blocks + a->service, 1);
+  std::chrono::steady_clock::time_point lp0;
+  if (g_launch_profile.on) lp0 = std::chrono::steady_clock::now();
+  const hipError_t le = c->storage == ABD_STORE_F32 ? launch_train<float>(cb, xc, grid, lds, pp.st, *a) : launch_train<double>(cb, xc, grid, lds, pp.st, *a);
+  if (g_launch_profile.on) {
+    g_launch_profile.eval_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - lp0).count();
+    g_launch_profile.evals++;
+  }
+  HIP_TRY(le);
+  return ABD_OK;
 }
 
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors) {

@@ -115,6 +115,7 @@ struct abd_ctx {
   int storage = ABD_STORE_F64;
   bool dense = false;
   bool xc_ok = false;  // dense and both antigens have split panels
+  int xc_max_cb = 1;   // launches with at most this many chains per workgroup read them
   bool ignore_pcr = false;
   int n_slots = 0;
   int n_cu = 256;
@@ -227,6 +228,8 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
                  int force_pipe = -1, double* seqp = nullptr);
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true);
 int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms, double* seqp = nullptr);
+int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* a);
+int dense_blocks(const abd_ctx* c, int cpw, int share = 0, int grid_rows = 1);
 
 // ---- abd_gibbs.hip
 int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta, uint64_t seed, uint32_t sweep,

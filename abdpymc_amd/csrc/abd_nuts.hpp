@@ -224,6 +224,11 @@ struct Nuts {
   double rho[D], log_w = 0;
   double prop_q[D], prop_g[D], prop_lp = 0;
   int depth = 0, dir = 1, n_leaf = 0, n_target = 1;
+  // the directions of ALL doublings of a transition are drawn when it begins (bit d: the doubling at depth d goes forward):
+  // a device that takes a chain's leapfrogs one after the other (abd_train.hpp) can then go on into the next half by
+  // itself, while the host's tree logic follows behind on the records
+  uint32_t dir_bits = 0;
+  double p0_pending[D];  // begin_draw .. begin_finish: the momentum drawn for a transition whose start point is still out for evaluation
   double sub_rho[D], sub_log_w = 0;
   double sub_q[D], sub_g[D], sub_lp = 0;
   double p_ckpt[MAX_DEPTH][D], rho_ckpt[MAX_DEPTH][D];
@@ -306,10 +311,21 @@ struct Nuts {
     }
   }
 
-  void begin() {
+  // begin() in two parts, for a driver that has to evaluate the start point first (the discrete state changed under the
+  // chain: abd.py:922's compound step): begin_draw() draws what the transition needs from the random stream,
+  // begin_finish() starts the tree once lp and g at q are known (set_point)
+  void begin_draw() {
     if (max_depth > MAX_DEPTH) max_depth = MAX_DEPTH;
+    draw_momentum(p0_pending);
+    dir_bits = (uint32_t)(rng.next() >> 32);
+  }
+  void begin() {
+    begin_draw();
+    begin_finish();
+  }
+  void begin_finish() {
     double p0[D];
-    draw_momentum(p0);
+    std::memcpy(p0, p0_pending, sizeof(p0));
     h0 = -lp + kinetic(p0);
     std::memcpy(left.q, q, sizeof(q));
     std::memcpy(left.p, p0, sizeof(p0));
@@ -343,14 +359,23 @@ struct Nuts {
   // next_q / next_p_half: the next point of the half and its half-kicked momentum as the device computed them (the same
   // operations as stage_leapfrog, diagonal metric); adopted instead of the host's own, so that what the chain records is
   // exactly what was evaluated
-  void feed(double lp1, const double* g1, const double* next_q = nullptr, const double* next_p_half = nullptr) {
+  // across_halves: the device also went on into the next half by itself (abd_train.hpp: it knows dir_bits), so its next
+  // point is adopted there too
+  void feed(double lp1, const double* g1, const double* next_q = nullptr, const double* next_p_half = nullptr, bool across_halves = false) {
     const int half_before = depth;
     feed_(lp1, g1);
-    if (next_q && active && depth == half_before && n_leaf > 0) {
+    if (next_q && active && (across_halves || (depth == half_before && n_leaf > 0))) {
       std::memcpy(req_q, next_q, sizeof(req_q));
       std::memcpy(p_half, next_p_half, sizeof(p_half));
     }
   }
+  // the first point of the transition as the device staged it (see feed)
+  void adopt_request(const double* next_q, const double* next_p_half) {
+    std::memcpy(req_q, next_q, sizeof(req_q));
+    std::memcpy(p_half, next_p_half, sizeof(p_half));
+  }
+  // leapfrogs a transition that starts now can take at most
+  int max_leaves() const { return (1 << max_depth) - 1; }
 
  private:
   void feed_(double lp1, const double* g1) {
@@ -425,7 +450,7 @@ struct Nuts {
   }
 
   void start_half() {
-    dir = rng.uniform() < 0.5 ? -1 : 1;
+    dir = (dir_bits >> depth) & 1u ? 1 : -1;
     cur = dir < 0 ? left : right;
     n_leaf = 0;
     n_target = 1 << depth;
@@ -490,8 +515,13 @@ struct AdaptiveNuts {
   bool tuning() const { return it < tune; }
   // start the transition of iteration `it`
   void begin() {
+    begin_draw();
+    nuts.begin_finish();
+  }
+  // ... in two parts (Nuts::begin_draw / begin_finish), for a driver that evaluates the start point in between
+  void begin_draw() {
     nuts.max_depth = (it < tune && it < 200 && early_max_depth < max_depth_full) ? early_max_depth : max_depth_full;
-    nuts.begin();
+    nuts.begin_draw();
   }
   // call when the transition of iteration `it` has finished
   void end_transition() {

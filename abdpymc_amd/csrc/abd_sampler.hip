@@ -4,6 +4,8 @@
 #include "abd_host.hpp"
 #include "abd_nuts.hpp"
 
+#include <deque>
+
 struct abd_sampler {
   abd_ctx* c = nullptr;
   int n = 0;
@@ -39,6 +41,25 @@ struct abd_sampler {
     int queued_in_half = 0;          // launches queued for the half that is being built
   };
   std::vector<TrainUnit> tu;
+  // Leapfrog trains of dense cohorts (abd_types.hpp: TrainChain; abd_train.hpp): units of 1, 2 or 4 chains share their
+  // launches, the device goes on from one half of a tree into the next by itself, the host's tree logic follows behind on
+  // the records, and a chain's sweep runs on a stream of its own beside the unit's launches for the other chains.
+  bool dtrains = false;
+  int dtrain_blocks = 0;     // workgroups (with a range) of a unit's launch: the unit's fixed shape
+  int dtrain_lookahead = 3;  // steps of a unit the host keeps queued ahead of the oldest record it has not seen
+  struct DChain {
+    TrainChain* st = nullptr;        // device
+    TrainRecord* ring_h = nullptr;   // mapped host memory [ABD_TRAIN_RING] ...
+    TrainRecord* ring_d = nullptr;   // ... as the device sees it
+    TrainBegin* begin_h = nullptr;   // mapped host memory [kBeginBlocks]
+    TrainBegin* begin_d = nullptr;
+    hipStream_t side = nullptr;      // the chain's sweep and its recording kernels
+    hipEvent_t sweep_done = nullptr;
+    int64_t n_rec = 0;               // records the steps queued so far produce (index of the next one)
+    int64_t n_begin = 0;             // transitions handed over so far
+  };
+  static constexpr int kBeginBlocks = 4;
+  std::vector<DChain> dc;
 };
 
 namespace {
@@ -60,6 +81,35 @@ int train_alloc(abd_sampler* s) {
     std::memset(t.rec_h, 0, abd_sampler::kTrainRing * sizeof(TrainRecord));
     HIP_TRY(hipHostGetDevicePointer((void**)&t.rec_d, t.rec_h, 0));
   }
+  return ABD_OK;
+}
+
+void dtrain_free(abd_sampler* s) {
+  for (auto& d : s->dc) {
+    if (d.st) (void)hipFree(d.st);
+    if (d.ring_h) (void)hipHostFree(d.ring_h);
+    if (d.begin_h) (void)hipHostFree(d.begin_h);
+    if (d.sweep_done) (void)hipEventDestroy(d.sweep_done);
+    if (d.side) (void)hipStreamDestroy(d.side);
+  }
+  s->dc.clear();
+}
+
+int dtrain_alloc(abd_sampler* s) {
+  s->dc.resize((size_t)s->n);
+  for (auto& d : s->dc) {
+    HIP_TRY(hipMalloc(&d.st, sizeof(TrainChain)));
+    HIP_TRY(hipMemset(d.st, 0, sizeof(TrainChain)));
+    HIP_TRY(hipHostMalloc((void**)&d.ring_h, ABD_TRAIN_RING * sizeof(TrainRecord), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(d.ring_h, 0, ABD_TRAIN_RING * sizeof(TrainRecord));
+    HIP_TRY(hipHostGetDevicePointer((void**)&d.ring_d, d.ring_h, 0));
+    HIP_TRY(hipHostMalloc((void**)&d.begin_h, abd_sampler::kBeginBlocks * sizeof(TrainBegin), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(d.begin_h, 0, abd_sampler::kBeginBlocks * sizeof(TrainBegin));
+    HIP_TRY(hipHostGetDevicePointer((void**)&d.begin_d, d.begin_h, 0));
+    HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.sweep_done, hipEventDisableTiming));
+  }
+  HIP_TRY(hipDeviceSynchronize());
   return ABD_OK;
 }
 
@@ -193,10 +243,13 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   const bool trains_ok = (c->dense || c->obs_lanes) && c->dense_own_sum && opts->dense_metric == 0 && env_int("ABD_SAMPLER_TRAINS", 1) != 0;
   int dense_unit = 1;
   while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
-  if (trains_ok && n <= 8) dense_unit = 1;
-  s->unit = (c->dense && (int64_t)c->G * c->N >= 500000) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
+  // dense trains: units of 1, 2 or 4 chains (abd_sampler::dtrains)
+  s->dtrains = trains_ok && c->dense;
+  if (s->dtrains) dense_unit = n >= 16 ? 4 : (n >= 3 ? 2 : 1);
+  s->unit = (c->dense && ((int64_t)c->G * c->N >= 500000 || s->dtrains)) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
   s->unit = env_int("ABD_SAMPLER_UNIT", s->unit);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
+  if (s->dtrains && s->unit != 1 && s->unit != 2 && s->unit != 4) s->dtrains = false;  // (a train unit is a workgroup's waves)
 
   // several units' launches are in flight: one workgroup per CU each, whatever the number of units -- a unit's numbers
   // must not depend on it
@@ -205,7 +258,17 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // the starting points through the launch shape the units will use
   rc = hipSetDevice(c->device) == hipSuccess ? flush_ring(c) : fail(ABD_ERR_HIP, "hipSetDevice failed");
   if (!rc && (n + s->unit - 1) / s->unit > 1 && tune_int("ABD_PROBE_QUEUES", 1) != 0) rc = probe_stream_queues(c);
-  s->trains = trains_ok && s->unit == 1;
+  s->trains = trains_ok && !c->dense && s->unit == 1;
+  if (s->dtrains) {
+    // the unit's launch shape: the chip's workgroup slots (4 per CU) divided among the units that are in flight together
+    const int n_units = (n + s->unit - 1) / s->unit;
+    const int per_cu = std::max(1, std::min(c->dbpc, c->dbpc / std::min(n_units, 4)));
+    s->dtrain_blocks = dense_blocks(c, s->unit, 0, 1);                      // (the cap that keeps ranges >= kMinRows rows)
+    s->dtrain_blocks = std::min(s->dtrain_blocks, c->n_cu * per_cu);
+    if (const int tb = tune_int("ABD_TRAIN_BLOCKS_PER_CU", 0)) s->dtrain_blocks = std::max(1, std::min({c->n_cu * tb, c->blocks_max, dense_blocks(c, s->unit, 0, 1)}));
+    s->dtrain_lookahead = std::max(2, std::min(ABD_TRAIN_RING / 2, tune_int("ABD_TRAIN_LOOKAHEAD", 3)));
+    if (!rc) rc = dtrain_alloc(s);
+  }
   s->lookahead = std::max(0, std::min(abd_sampler::kTrainRing - 2, tune_int("ABD_TRAIN_LOOKAHEAD", 8)));
   if (!rc && s->trains) rc = train_alloc(s);
   for (int u = 0, lo = 0; lo < n && !rc; ++u, lo += s->unit) {
@@ -237,12 +300,14 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   }
   if (rc) {
     train_free(s);
+    dtrain_free(s);
     delete s;
     return rc;
   }
   for (int k = 0; k < n; ++k) {
     if (!std::isfinite(s->lp[(size_t)k])) {
       train_free(s);
+      dtrain_free(s);
       delete s;
       return fail(ABD_ERR_ARG, "logp at the starting point of chain %d is not finite", chains[k]);
     }
@@ -257,6 +322,7 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     if (e != hipSuccess) {
       if (s->d_sums) (void)hipFree(s->d_sums);
       train_free(s);
+      dtrain_free(s);
       delete s;
       return fail(ABD_ERR_HIP, "sampler sums: %s", hipGetErrorString(e));
     }
@@ -267,10 +333,11 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
 
 void abd_sampler_destroy(abd_sampler* s) {
   if (!s) return;
-  if (!s->tu.empty()) {
+  if (!s->tu.empty() || !s->dc.empty()) {
     (void)hipSetDevice(s->c->device);
     (void)hipDeviceSynchronize();  // launches of a half that ended early may still be on their way
     train_free(s);
+    dtrain_free(s);
   }
   if (s->d_sums || s->d_rec_mu || s->d_rec_i8) {
     (void)hipSetDevice(s->c->device);
@@ -343,6 +410,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   abd_ctx* c = s->c;
   const int n = s->n, B = s->unit;
   const int n_units = (n + B - 1) / B;
+  const int64_t thin = recording ? std::max<int64_t>(1, rec->thin) : 1;  // iterations 0, thin, 2 thin, ... of the call are recorded
   enum { EVAL, POST, DONE };
   struct Unit {
     int lo = 0, hi = 0, m = 0, state = EVAL;
@@ -457,13 +525,13 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     for (int j = un.lo; j < un.hi; ++j) {
       // running sums and the draw's record share one launch of the Deterministics kernel where both are wanted
       double* sums = (draw && s->d_sums) ? s->d_sums + (size_t)j * 3 * (size_t)c->G * c->N : nullptr;
-      if (recording) {
+      if (recording && un.k % thin == 0) {
         if (int rc = record_stage_chain(s, rec, j, un.staged, st, sums)) return rc;
       } else if (sums) {
         if (int rc = accumulate_chain(s, j, st)) return rc;
       }
     }
-    if (recording && ++un.staged == s->rec_chunk) {
+    if (recording && un.k % thin == 0 && ++un.staged == s->rec_chunk) {
       for (int j = un.lo; j < un.hi; ++j)
         if (int rc = record_flush_chain(s, rec, j, un.flushed_to, un.staged, st)) return rc;
       un.flushed_to += un.staged;
@@ -645,6 +713,291 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
   return ABD_OK;
 }
 
+// ---- dense cohorts: the compound step over leapfrog-train units (abd_sampler::dtrains) ----
+// One host thread.  Per unit (1, 2 or 4 consecutive chains, stream unit_pipe(u)): launches are queued `dtrain_lookahead`
+// steps ahead; every launch takes each chain of the unit that is inside a tree one leapfrog further (TrainChainArgs STEP),
+// hands a new transition to a chain that is waiting for one (BEGIN, read by the launch's last workgroup) and leaves the
+// others alone.  Per chain: the records are taken in order and fed to the NUTS state machine, which runs BEHIND the device;
+// when it finds the tree ended, the steps still queued for the chain are stale (their records are never looked at) and the
+// chain's iteration goes on beside the unit's launches: sweep + counts on the chain's own stream, then -- the discrete
+// state has changed -- a BEGIN whose first step evaluates the start point (EVAL0) before the tree starts from it.
+// Nothing a chain computes depends on the other chains or on timing: launch shape and step order are fixed per chain.
+int sampler_run_trains(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec, bool recording) {
+  abd_ctx* c = s->c;
+  const int n = s->n, B = s->unit;
+  const int n_units = (n + B - 1) / B;
+  const int64_t thin = recording ? std::max<int64_t>(1, rec->thin) : 1;
+  enum { NEED_BEGIN, TREE, SWEEP, DONE };
+  struct Step {
+    int64_t idx;     // record index
+    uint32_t epoch;  // the transition it belongs to
+    bool eval0;
+  };
+  struct Run {
+    int state = DONE;
+    int64_t k = 0;           // iterations completed in this call
+    uint32_t epoch = 0;      // counts the chain's transitions: steps of an earlier one are stale
+    int parity = 0;          // use_slot of the chain's next step
+    int steps_queued = 0, max_steps = 0;
+    bool eval_first = false, eval_only = false;
+    int begin_block = 0;
+    int pend_slot = -1;      // the last step left its record beside pt[pend_slot] ...
+    int64_t pend_idx = 0;    // ... for the next launch's service workgroup to pass on
+    std::deque<Step> fifo;
+    int64_t staged = 0, flushed_to = 0;  // recording: draws staged on the device / copied out
+  };
+  std::vector<Run> runs((size_t)n);
+  HIP_TRY(hipSetDevice(c->device));
+  if (int frc = flush_ring(c)) return frc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // whatever the caller queued on the context's stream comes first
+  static const bool profile = env_int("ABD_SAMPLER_PROFILE", 0) != 0;
+  using clk = std::chrono::steady_clock;
+  g_launch_profile = LaunchProfile();
+  g_launch_profile.on = profile;
+  long n_launches = 0, n_records = 0, n_stale = 0;
+  const clk::time_point t_begin = clk::now();
+
+  auto stage_begin = [&](int j, bool eval_first, bool eval_only) {
+    // hand chain j's next transition to the device: begin_draw() has been called (momentum and directions drawn)
+    Run& r = runs[(size_t)j];
+    abd_sampler::DChain& d = s->dc[(size_t)j];
+    const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+    r.begin_block = (int)(d.n_begin++ % abd_sampler::kBeginBlocks);
+    TrainBegin& b = d.begin_h[r.begin_block];
+    std::memcpy(b.q0, nu.q, sizeof b.q0);
+    std::memcpy(b.p0, nu.p0_pending, sizeof b.p0);
+    std::memcpy(b.g0, nu.g, sizeof b.g0);
+    std::memcpy(b.inv_mass, nu.inv_mass, sizeof b.inv_mass);
+    b.eps = nu.eps;
+    b.dirs = nu.dir_bits;
+    b.max_depth = eval_only ? 0 : nu.max_depth;
+    b.eval_first = eval_first ? 1 : 0;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    r.eval_first = eval_first;
+    r.eval_only = eval_only;
+    r.state = NEED_BEGIN;
+  };
+  // outputs of iteration r.k of chain j (point and discrete state are final), its recording, then the next transition
+  auto iteration_done = [&](int j, bool with_counts) -> int {
+    Run& r = runs[(size_t)j];
+    abd_sampler::DChain& d = s->dc[(size_t)j];
+    const abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+    if (theta) std::memcpy(theta + ((size_t)j * n_iter + r.k) * ABD_N_THETA, nu.q, sizeof(double) * ABD_N_THETA);
+    if (stats) {
+      double* o = stats + ((size_t)j * n_iter + r.k) * ABD_N_STATS;
+      o[ABD_STAT_LP] = nu.lp;
+      o[ABD_STAT_TREE_DEPTH] = nu.stats.tree_depth;
+      o[ABD_STAT_N_STEPS] = nu.stats.n_steps;
+      o[ABD_STAT_MEAN_TREE_ACCEPT] = nu.stats.mean_tree_accept;
+      o[ABD_STAT_STEP_SIZE] = nu.stats.step_size;
+      o[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
+      o[ABD_STAT_ENERGY] = nu.stats.energy;
+      o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
+      o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
+      o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+    }
+    // running sums and the draw's record: on the chain's own stream, behind its sweep and in front of the next one (they read
+    // the discrete state; the point goes by value)
+    const bool draw = s->it + r.k >= s->o.tune;
+    double* sums = (draw && s->d_sums) ? s->d_sums + (size_t)j * 3 * (size_t)c->G * c->N : nullptr;
+    if (recording && r.k % thin == 0) {
+      if (int rc = record_stage_chain(s, rec, j, r.staged, d.side, sums)) return rc;
+      if (++r.staged == s->rec_chunk) {
+        if (int rc = record_flush_chain(s, rec, j, r.flushed_to, r.staged, d.side)) return rc;
+        r.flushed_to += r.staged;
+        r.staged = 0;
+      }
+    } else if (sums) {
+      if (int rc = accumulate_chain(s, j, d.side)) return rc;
+    }
+    r.k += 1;
+    if (r.k == n_iter) {
+      r.state = DONE;
+      if (recording)
+        if (int rc = record_flush_chain(s, rec, j, r.flushed_to, r.staged, d.side)) return rc;
+      r.staged = 0;
+    }
+    return ABD_OK;
+  };
+  // chain j's tree has ended (the NUTS state machine holds the new point): adaptation, then the sweep or the next transition
+  auto transition_end = [&](int j) -> int {
+    Run& r = runs[(size_t)j];
+    abd_sampler::DChain& d = s->dc[(size_t)j];
+    r.epoch += 1;  // what is still queued for the chain belongs to a tree that is over
+    s->ch[(size_t)j].end_transition();
+    if (s->o.gibbs) {
+      const int32_t id = s->chains[(size_t)j];
+      if (int rc = enqueue_gibbs(c, 1, &id, s->ch[(size_t)j].nuts.q, (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + r.k), (uint32_t)s->o.chain_offset,
+                                 d.side, c->d_counts_chain + 2 * (size_t)j, c->d_work + c->n_slots + j, nullptr))
+        return rc;
+      HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)j, c->d_counts_chain + 2 * (size_t)j, 2 * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, d.side));
+      HIP_TRY(hipEventRecord(d.sweep_done, d.side));
+      r.state = SWEEP;
+      return ABD_OK;
+    }
+    if (int rc = iteration_done(j, false)) return rc;
+    if (r.state != DONE) {
+      s->ch[(size_t)j].begin();  // (logp and gradient at the new point are the proposal's)
+      stage_begin(j, false, false);
+    }
+    return ABD_OK;
+  };
+
+  for (int j = 0; j < n; ++j) {
+    Run& r = runs[(size_t)j];
+    r.flushed_to = recording ? rec->first : 0;
+    if (n_iter == 0) continue;
+    s->ch[(size_t)j].begin();
+    stage_begin(j, false, false);  // logp and gradient at the chain's point are known (abd_sampler_create, or the run before)
+  }
+
+  int rc_loop = ABD_OK;
+  for (long spins = 0; rc_loop == ABD_OK;) {
+    bool any = false, progressed = false;
+    for (int u = 0; u < n_units && rc_loop == ABD_OK; ++u) {
+      const int lo = u * B, hi = std::min(n, lo + B);
+      // ---- take the records that have landed ----
+      for (int j = lo; j < hi && rc_loop == ABD_OK; ++j) {
+        Run& r = runs[(size_t)j];
+        abd_sampler::DChain& d = s->dc[(size_t)j];
+        abdnuts::Nuts& nu = s->ch[(size_t)j].nuts;
+        while (!r.fifo.empty() && rc_loop == ABD_OK) {
+          const Step e = r.fifo.front();
+          if (e.epoch != r.epoch) {  // a step the device took beyond the end of its tree
+            r.fifo.pop_front();
+            ++n_stale;
+            continue;
+          }
+          const TrainRecord& tr = d.ring_h[e.idx % ABD_TRAIN_RING];
+          if (*(volatile const double*)&tr.tag != (double)(e.idx + 1)) break;
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          r.fifo.pop_front();
+          progressed = true;
+          ++n_records;
+          if (e.eval0) {
+            // logp and gradient at the start point under the new discrete state: the iteration the sweep closed is complete
+            nu.set_point(tr.lp, tr.g);
+            if ((rc_loop = iteration_done(j, true)) != ABD_OK) break;
+            if (r.state == DONE) break;  // (the evaluation was all this BEGIN asked for)
+            nu.begin_finish();
+            nu.adopt_request(tr.next_theta, tr.next_p_half);
+          } else {
+            nu.feed(tr.lp, tr.g, tr.next_theta, tr.next_p_half, true);
+            if (!nu.active) rc_loop = transition_end(j);
+          }
+        }
+      }
+      if (rc_loop != ABD_OK) break;
+      // ---- sweeps that have finished: the next transition starts with an evaluation at the new state ----
+      for (int j = lo; j < hi; ++j) {
+        Run& r = runs[(size_t)j];
+        if (r.state != SWEEP) continue;
+        const hipError_t qe = hipEventQuery(s->dc[(size_t)j].sweep_done);
+        if (qe == hipErrorNotReady) continue;
+        if (qe != hipSuccess) {
+          rc_loop = fail(ABD_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(qe));
+          break;
+        }
+        progressed = true;
+        const bool last = r.k + 1 == n_iter;
+        if (!last) s->ch[(size_t)j].begin_draw();
+        stage_begin(j, true, last);
+      }
+      if (rc_loop != ABD_OK) break;
+      // ---- keep the unit's launches queued ahead ----
+      for (;;) {
+        size_t out = 0;
+        bool any_begin = false, any_step = false;
+        for (int j = lo; j < hi; ++j) {
+          const Run& r = runs[(size_t)j];
+          out = std::max(out, r.fifo.size());
+          any_begin |= r.state == NEED_BEGIN;
+          any_step |= r.state == TREE && r.steps_queued < r.max_steps;
+        }
+        if (!any_begin && !(any_step && out < (size_t)s->dtrain_lookahead)) break;
+        const bool step_now = out < (size_t)s->dtrain_lookahead;
+        DenseTrainArgs a;
+        std::memset(&a, 0, sizeof a);
+        for (int k = 0; k < ABD_TRAIN_CB; ++k) a.tc[k].fwd_slot = -1;  // (a unit may have fewer chains than its shape: those slots stay SKIP)
+        for (int j = lo; j < hi; ++j) {
+          Run& r = runs[(size_t)j];
+          abd_sampler::DChain& d = s->dc[(size_t)j];
+          const ChainSlot& slot = c->slots[(size_t)s->chains[(size_t)j]];
+          TrainChainArgs& tc = a.tc[j - lo];
+          tc.st = d.st;
+          tc.ring = d.ring_d;
+          tc.begin = d.begin_d;
+          tc.iw = slot.iw;
+          tc.cnt = slot.cnt;
+          tc.waner = slot.waner;
+          tc.action = ABD_TR_SKIP;
+          tc.fwd_slot = -1;
+          if (r.state == NEED_BEGIN) {
+            tc.action = ABD_TR_BEGIN;
+            tc.begin = d.begin_d + r.begin_block;
+            r.state = TREE;
+            r.parity = 0;
+            r.steps_queued = 0;
+            r.max_steps = (r.eval_first ? 1 : 0) + (r.eval_only ? 0 : s->ch[(size_t)j].nuts.max_leaves());
+            r.pend_slot = -1;  // (a record left there belongs to steps beyond the end of the last tree)
+          } else if (r.state == TREE && r.steps_queued < r.max_steps && step_now) {
+            tc.action = ABD_TR_STEP;
+            tc.use_slot = r.parity;
+            tc.rec_idx = d.n_rec++;
+            tc.own = r.steps_queued + 1 == r.max_steps ? 1 : 0;  // nothing can follow the tree's last possible leaf
+            if (r.pend_slot >= 0) {
+              tc.fwd_slot = r.pend_slot;
+              tc.fwd_idx = r.pend_idx;
+            }
+            r.pend_slot = tc.own ? -1 : (r.parity ^ 1);
+            r.pend_idx = tc.rec_idx;
+            r.fifo.push_back(Step{tc.rec_idx, r.epoch, r.eval_first && r.steps_queued == 0});
+            r.parity ^= 1;
+            r.steps_queued += 1;
+          } else if (r.pend_slot >= 0) {
+            tc.fwd_slot = r.pend_slot;  // the chain sits this launch out; its last record still goes to the host
+            tc.fwd_idx = r.pend_idx;
+            r.pend_slot = -1;
+          }
+        }
+        if ((rc_loop = enqueue_dense_train(c, unit_pipe(c, u), B, s->dtrain_blocks, &a)) != ABD_OK) break;
+        ++n_launches;
+        progressed = true;
+      }
+      for (int j = lo; j < hi; ++j) any |= runs[(size_t)j].state != DONE;
+    }
+    if (rc_loop != ABD_OK || !any) break;
+    if (progressed) {
+      spins = 0;
+    } else if (++spins > 40000000) {
+      // nothing has moved for seconds: a record that never got its tag
+      __atomic_fetch_add(&c->wait_fallbacks, (int64_t)1, __ATOMIC_RELAXED);
+      (void)hipDeviceSynchronize();
+      rc_loop = fail(ABD_ERR_STATE, "the native sampler's leapfrog trains stalled: a record never received its tag");
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  // what the device still has queued beyond the ends of the last trees must be through before anybody reuses the chains' state
+  for (int u = 0; u < n_units; ++u) (void)hipStreamSynchronize(c->pipe[unit_pipe(c, u)].st);
+  for (int j = 0; j < n; ++j) (void)hipStreamSynchronize(s->dc[(size_t)j].side);
+  g_launch_profile.on = false;
+  if (rc_loop != ABD_OK) return rc_loop;
+  if (profile) {
+    const double wall = std::chrono::duration<double>(clk::now() - t_begin).count();
+    std::fprintf(stderr, "abd sampler (trains): %d units of %d chains, %ld launches, %ld records (%ld stale steps) in %.3f s; %.2f us inside the "
+                 "launch call per launch\n", n_units, B, n_launches, n_records, n_stale, wall,
+                 g_launch_profile.evals ? 1e6 * g_launch_profile.eval_s / g_launch_profile.evals : 0.0);
+  }
+  for (int pi = 1; pi < c->n_streams; ++pi) c->pipe[pi].busy = true;
+  if (int jrc = join_pipes(c)) return jrc;
+  const int64_t first_draw = std::max<int64_t>(s->it, s->o.tune);
+  if (s->d_sums && s->it + n_iter > first_draw) s->n_accumulated += s->it + n_iter - first_draw;
+  s->it += n_iter;
+  return ABD_OK;
+}
+
 }  // namespace
 
 int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double* stats, const abd_record* rec) {
@@ -654,9 +1007,11 @@ int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double
   const int n = s->n;
   const bool recording = rec && (rec->i_raw || rec->ab_s_waner || rec->i || rec->ab_n_mu || rec->ab_s_mu);
   if (recording) {
-    if (rec->first < 0 || rec->first + n_iter > rec->capacity)
+    if (rec->thin < 0) return fail(ABD_ERR_ARG, "record: thin=%lld is negative", (long long)rec->thin);
+    const int64_t thin = std::max<int64_t>(1, rec->thin), n_rec = (n_iter + thin - 1) / thin;  // iterations 0, thin, 2 thin, ... of the call
+    if (rec->first < 0 || rec->first + n_rec > rec->capacity)
       return fail(ABD_ERR_ARG, "record: draws [%lld, %lld) do not fit capacity %lld", (long long)rec->first,
-                  (long long)(rec->first + n_iter), (long long)rec->capacity);
+                  (long long)(rec->first + n_rec), (long long)rec->capacity);
     if (!s->d_rec_mu) {
       HIP_TRY(hipSetDevice(c->device));
       const size_t cells = (size_t)c->G * c->N;
@@ -674,6 +1029,7 @@ int abd_sampler_run_record(abd_sampler* s, int64_t n_iter, double* theta, double
       s->d_rec_i8 = i8;
     }
   }
+  if (s->dtrains) return sampler_run_trains(s, n_iter, theta, stats, rec, recording);
   return sampler_run_units(s, n_iter, theta, stats, rec, recording);
 }
 

@@ -8,6 +8,7 @@
 #define __device__
 #define __forceinline__ inline
 #endif
+#include <stddef.h>
 #include <stdint.h>
 
 #define ABD_MAXT 4          // 64-gap words per individual the register-resident kernels are built for by default (G <= 256) ...
@@ -89,6 +90,80 @@ struct TrainArgs {
   double fwd_tag;           // ... under the predecessor's tag; nullptr: the predecessor wrote its own
   double inv_mass[ABD_NT];  // diagonal of M^-1
   TrainPoint first;
+};
+
+// ---- leapfrog trains of dense cohorts (abd_train.hpp; abd_sampler.hip) ----
+// A train UNIT is 1, 2 or 4 chains that share their launches: one launch takes every stepping chain of the unit one
+// leapfrog further (the chains read the same panel rows, once).  What persists between launches lives in device memory,
+// one TrainChain per chain, and the launch's last workgroup runs the chain's state machine on it: assemble logp and
+// gradient, finish the leapfrog, and -- the directions of all doublings of a transition are drawn when it begins
+// (abd_nuts.hpp: dir_bits) -- go on into the next half of the tree when one is complete.  The host's tree logic follows
+// behind on the records and stops asking for steps when the tree has ended; a new transition is handed over in a TrainBegin
+// block (mapped host memory), read by the last workgroup of a launch in which the chain does not step.
+#define ABD_TRAIN_CB 4      // chains per unit at most (= waves of a workgroup: wave k of the last workgroup runs chain k's state machine)
+#define ABD_TRAIN_RING 64   // records per chain in mapped host memory
+enum { ABD_TR_SKIP = 0, ABD_TR_STEP = 1, ABD_TR_BEGIN = 2 };  // what a launch does with a chain of its unit
+enum { ABD_PH_IDLE = 0, ABD_PH_EVAL0 = 1, ABD_PH_LEAF = 2 };  // TrainChain::phase
+struct TrainEnd {            // one end of the trajectory: point, momentum, gradient (abd_nuts.hpp: Phase)
+  double q[ABD_NT], p[ABD_NT], g[ABD_NT];
+};
+struct TrainBegin {          // a new transition, staged by the host (abd_nuts.hpp: begin_draw / begin_finish)
+  double q0[ABD_NT], p0[ABD_NT], g0[ABD_NT];  // g0 is not read when eval_first
+  double inv_mass[ABD_NT];
+  double eps;
+  uint32_t dirs;             // bit d: the doubling at depth d goes forward
+  int32_t max_depth;         // 0: no leapfrog at all (eval_first: just the evaluation at q0)
+  int32_t eval_first;        // 1: the discrete state changed under the chain (abd.py:922: the sweep): evaluate at q0 first,
+  int32_t pad_;              //    record that, then start the tree from (q0, p0, gradient found)
+};
+struct TrainChain {
+  TrainPoint pt[2];          // pt[s]: the point a step launch with use_slot = s evaluates; written by the launch before it
+  TrainEnd end[2];           // [0] the backward end of the trajectory, [1] the forward end
+  double inv_mass[ABD_NT];
+  double eps;
+  uint32_t dirs;
+  int32_t max_depth;
+  int32_t phase, depth, n_leaf, n_target, dir;  // dir: +1 / -1, direction of the half being built
+  int32_t pad_;
+};
+struct TrainChainArgs {      // one chain of a train launch
+  TrainChain* st;
+  TrainRecord* ring;         // mapped host memory, [ABD_TRAIN_RING]: record k at ring[k % ABD_TRAIN_RING] under tag k + 1
+  const TrainBegin* begin;   // mapped host memory (action BEGIN)
+  const uint64_t* iw;        // the chain slot's discrete state (ChainPar)
+  const long long* cnt;
+  const int8_t* waner;
+  int32_t action;            // ABD_TR_*
+  int32_t use_slot;          // STEP: the point is st->pt[use_slot]; the next one goes to pt[use_slot ^ 1]
+  int32_t own;               // STEP: the launch writes the step's record itself (nothing queued behind it would pass it on)
+  int32_t fwd_slot;          // >= 0: the chain's previous step left its record beside pt[fwd_slot]: the service workgroup passes it on
+  int64_t rec_idx;           // STEP: index of the record this step produces
+  int64_t fwd_idx;           // fwd_slot >= 0: index of the record passed on
+};
+struct DenseTrainArgs {
+  const void* yx_n;          // panels, as in EvalArgs
+  const void* yx_s;
+  const void* od_n;
+  const void* od_s;
+  const uint8_t* xc_n;
+  const uint8_t* xc_s;
+  const double* dict_n;
+  const double* dict_s;
+  const uint64_t* vw;
+  const double* exp2_tab;
+  double* partials;          // [CB][workgroups][ABD_NOUT]
+  unsigned int* fin_count;   // one zeroed counter: the workgroup that counts in last runs the state machines
+#ifdef ABD_STAMPS
+  unsigned long long* stamps;
+#endif
+  double prior_const;
+  int32_t n_dict_n, n_dict_s;
+  int32_t rg_base, rg_extra, rg_e_fin, rg_n_short;
+  uint32_t rg_g_magic;
+  int32_t xcd_remap;
+  int32_t service;           // 1: workgroup 0 has no range: it passes records on to the host (TrainChainArgs::fwd_slot)
+  int32_t G, N, n_lg, K_n, K_s;
+  TrainChainArgs tc[ABD_TRAIN_CB];
 };
 
 struct EvalArgs {

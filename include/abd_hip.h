@@ -226,6 +226,9 @@ int abd_sampler_run(abd_sampler* s, int64_t n_iter, double* theta, double* stats
 typedef struct abd_record {
   int64_t capacity;
   int64_t first;
+  int64_t thin;        /* 0 or 1: every iteration of the call is recorded; K > 1: iterations 0, K, 2K, ... of the call, at
+                          draws first, first + 1, ... (the reference thins afterwards, subsample_idata.py; at config 3 a
+                          draw is 36 MB per chain, so here it is done while sampling) */
   int8_t* i_raw;
   int8_t* ab_s_waner;
   int8_t* i;

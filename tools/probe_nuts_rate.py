@@ -35,6 +35,8 @@ else:
     states = [synthetic.make_chain_state(N, G, c) for c in range(C)]
     row = int(os.environ.get("ABD_PROBE_THETA_ROW", "0"))  # 5 with 25 rows: the starting points bench.py's NUTS run uses
     th0 = np.stack([synthetic.make_thetas(G, 25 if row else 1, c)[row] for c in range(C)])
+if os.environ.get("ABD_PROBE_SAME_STATE", "0") == "1":  # every chain on chain 0's discrete state (balanced trees: bench.py's `nuts`)
+    states = [states[0]] * C
 for c in range(C):
     ctx.set_discrete(c, *states[c])
 ta = float(os.environ.get("ABD_PROBE_TARGET_ACCEPT", "0.8"))  # closer to 1: smaller steps, longer trees

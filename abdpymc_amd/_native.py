@@ -79,9 +79,9 @@ class _Record(C.Structure):
     ]
 
 
-N_STATS = 10
+N_STATS = 11
 STAT_NAMES = ("lp", "tree_depth", "n_steps", "mean_tree_accept", "step_size", "diverging", "energy", "max_energy_error",
-              "gibbs_accepted", "gibbs_proposed")
+              "gibbs_accepted", "gibbs_proposed", "t_done")
 
 _lib = None
 

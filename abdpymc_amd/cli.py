@@ -33,6 +33,11 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--seed", help="Random seed.", type=int, default=0)
     parser.add_argument("--device", help="HIP device ordinal.", type=int, default=-1)
     parser.add_argument("--no_deterministics", help="Do not record i / ab_n_mu / ab_s_mu per draw.", action="store_true")
+    parser.add_argument("--no_discrete", help="Do not record i_raw / ab_s_waner per draw.", action="store_true")
+    parser.add_argument("--thin", "--record_every", dest="thin", type=int, default=1,
+                        help="Keep the per-draw (gap, ind) arrays of every K-th draw only (the 17 scalars, the statistics and the "
+                        "posterior means mean_i / mean_ab_n_mu / mean_ab_s_mu cover every draw).  Default 1; a run whose arrays "
+                        "exceed the host budget (ABD_RECORD_BUDGET_GB, default 8) is refused with the K that fits.")
     parser.add_argument("--dense_metric", help="Adapt a full mass matrix (PyMC's init='adapt_full') instead of a diagonal one.",
                         action="store_true")
     return parser
@@ -44,11 +49,22 @@ def write_posterior(res: dict, path: str, coords: dict) -> str:
     except ImportError:
         az = None
     if az is not None and path:
+        # (UNVERIFIED-OFFLINE: ArviZ is not importable where this was written)
         dims = {"i_raw": ["gap", "ind"], "i": ["gap", "ind"], "ab_n_mu": ["gap", "ind"], "ab_s_mu": ["gap", "ind"],
-                "ab_s_waner": ["ind"]}
-        post = {k: v for k, v in res.items() if not k.startswith("stat_") and k != "n_grad_evals"}
+                "ab_s_waner": ["ind"], "mean_i": ["chain", "gap", "ind"], "mean_ab_n_mu": ["chain", "gap", "ind"],
+                "mean_ab_s_mu": ["chain", "gap", "ind"]}
+        skip = ("n_grad_evals", "draw_index", "mean_i", "mean_ab_n_mu", "mean_ab_s_mu")
+        post = {k: v for k, v in res.items() if not k.startswith("stat_") and k not in skip}
         stats = {k[5:]: v for k, v in res.items() if k.startswith("stat_")}
-        idata = az.from_dict(posterior=post, sample_stats=stats, coords=coords, dims=dims)
+        means = {k: res[k] for k in ("mean_i", "mean_ab_n_mu", "mean_ab_s_mu") if k in res}
+        if "draw_index" in res and res["draw_index"].shape[1] != next(iter(stats.values())).shape[1]:
+            # --thin: an InferenceData has ONE draw axis, so the file holds the thinned draws of every variable (what
+            # abdpymc-subsample-idata makes of a full one); the posterior means over ALL draws travel as constant data
+            idx = res["draw_index"][0]
+            n_all = next(iter(stats.values())).shape[1]
+            post = {k: (v[:, idx] if v.shape[1] == n_all else v) for k, v in post.items()}
+            stats = {k: v[:, idx] for k, v in stats.items()}
+        idata = az.from_dict(posterior=post, sample_stats=stats, constant_data=means or None, coords=coords, dims=dims)
         az.to_netcdf(idata, path)  # abd.py:924
         return path
     out = (path or "abd_posterior") + ("" if str(path or "").endswith(".npz") else ".npz")
@@ -96,9 +112,11 @@ def main(argv=None) -> int:
         if a == b or a % max(1, b // 10) == 0:
             print(f"chain {first + c}: {a}/{b} iterations, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
 
+    if args.thin < 1:
+        raise SystemExit(f"--thin must be >= 1, got {args.thin}")
     res = sample(m, tune=args.tune, draws=args.draws, chains=mine, seed=args.seed,
-                 record_deterministics=not args.no_deterministics, progress=progress, chain_offset=first,
-                 dense_metric=args.dense_metric)  # abd.py:922
+                 record_deterministics=not args.no_deterministics, record_discrete=not args.no_discrete, progress=progress,
+                 chain_offset=first, dense_metric=args.dense_metric, thin=args.thin)  # abd.py:922
     name = m.ctx.device_name
     m.close()
     if world > 1:

@@ -426,6 +426,7 @@ void free_ctx(abd_ctx* c) {
   if (c->d_work) (void)hipFree(c->d_work);
   if (c->d_counts_chain) (void)hipFree(c->d_counts_chain);
   if (c->d_fin_count) (void)hipFree(c->d_fin_count);
+  if (c->d_train_count) (void)hipFree(c->d_train_count);
   if (c->h_counts_chain) (void)hipHostFree(c->h_counts_chain);
   if (c->d_det) (void)hipFree(c->d_det);
   for (auto& e : c->win_end)
@@ -511,9 +512,9 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   // the dense kernel addresses the gap rows of a piece (up to G of them) with a 32-bit scalar offset (abd_dense.hpp);
   // beyond 2^28 cells (fp64; 2^29 in fp32 storage) per GPU the cohort takes the observation-list kernels instead
   if ((int64_t)N * (d->storage == ABD_STORE_F32 ? 8 : 16) * (G + 2) >= ((int64_t)1 << 32)) c->dense = false;
-  // ... and splits the (lane group, gap) plane by 32-bit arithmetic: row / G by a 32-bit reciprocal is exact below 2^32 / G
-  // rows (abd_types.hpp: EvalArgs::rg_*; 6.8 M individuals at 200 gaps, 1 M at 512 -- beyond the limit above anyway)
-  if ((uint64_t)c->n_lg * (uint64_t)G * (uint64_t)G >= (1ull << 32)) c->dense = false;
+  // ... and splits the (lane group, gap) plane by 32-bit arithmetic: row / G by a 32-bit reciprocal must be exact for every
+  // row of the plane (abd_types.hpp: abd_div_magic_exact; 6.8 M individuals at 200 gaps -- beyond the limit above anyway)
+  if (!abd_div_magic_exact((uint64_t)c->n_lg * (uint64_t)G, (uint32_t)G)) c->dense = false;
   if (env_int("ABD_FORCE_SPARSE", 0)) c->dense = false;
   c->ignore_pcr = d->pcrpos == nullptr;
   c->n_slots = d->n_chain_slots;
@@ -640,6 +641,11 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipMalloc(&c->d_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long)));
   CREATE_TRY(hipMalloc(&c->d_fin_count, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
   CREATE_TRY(hipMemset(c->d_fin_count, 0, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
+  {
+    const size_t tc_bytes = (size_t)kMaxPipes * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE * sizeof(unsigned int);
+    CREATE_TRY(hipMalloc(&c->d_train_count, tc_bytes));
+    CREATE_TRY(hipMemset(c->d_train_count, 0, tc_bytes));
+  }
   c->dense_own_sum = env_int("ABD_DENSE_OWN_SUM", 1) != 0;
   CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->gibbs_v1 = env_int("ABD_GIBBS_V1", 0) != 0;

@@ -563,7 +563,7 @@ __device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, in
 __host__ __device__ inline size_t abd_dense_lds(int G, int cb, bool xc = false, bool train = false) {
   const size_t need = (size_t)cb * 2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
                       (size_t)ABD_EXP2_TAB * sizeof(double) + (xc ? (size_t)2 * ABD_XDICT * sizeof(double) : 0);
-  const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double) + (train ? (size_t)ABD_TRAIN_CB * ABD_TRAIN_SM * sizeof(double) : 0);
+  const size_t fin = train ? (size_t)ABD_TRAIN_CB * ABD_TRAIN_SM * sizeof(double) : (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
   return need > fin ? need : fin;
 }
 
@@ -824,29 +824,71 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
   int* flag = reinterpret_cast<int*>(red);  // the block reduction is done with: [CB] flags
   __syncthreads();
   if constexpr (TRAINK) {
-    // one counter for the launch: its last workgroup sums the rows of every chain that stepped and then runs the chains'
-    // state machines, wave k chain k's (abd_train.hpp)
+    // Count-in in two levels: with one counter a launch of 1 024 workgroups spends ~12 us in its 1 024 returning adds (they
+    // serialise, ~12 ns each), and its last workgroup would read 128 KB of rows per chain by itself.  Workgroup b belongs to
+    // shard b mod ABD_TRAIN_SHARDS; a shard's last arriver sums the shard's rows of every stepping chain (in range order) into
+    // one shard row and counts in at the top; the top's last arriver sums the shard rows (in shard order) and runs the
+    // chains' state machines, wave k chain k's (abd_train.hpp).  Fixed orders: the sums depend on the launch shape only.
+    // Hand-off as above: rows stored write-through by wave 0, drained, then the returning agent-scope add; re-read with sc1 loads.
+    const int shard = blk % ABD_TRAIN_SHARDS;
+    const int n_in_shard = (nblk - shard + ABD_TRAIN_SHARDS - 1) / ABD_TRAIN_SHARDS;
+    const int n_shards = min(nblk, ABD_TRAIN_SHARDS);
+    unsigned int* cnt_shard = a.fin_count + (1 + shard) * ABD_TRAIN_CNT_STRIDE;
+    double* shard_rows = a.partials + (int64_t)CB * nblk * ABD_NOUT;  // [CB][ABD_TRAIN_SHARDS][ABD_NOUT]
     if (wave == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(cnt_shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = old + 1u == (unsigned int)n_in_shard ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    const bool shard_last = flag[0] != 0;
+    __syncthreads();
+    if (!shard_last) return;
+    if (wave == 0) {
+      if (lane < CB * ABD_NOUT) {
+        const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
+        double v = 0.0;
+        if (a.tc[cc].action == ABD_TR_STEP) {
+          const double* col = a.partials + ((int64_t)cc * nblk + shard) * ABD_NOUT + k;
+          for (int i0 = 0; i0 < n_in_shard; i0 += 8) {
+            double q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              q[u] = i0 + u < n_in_shard ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_TRAIN_SHARDS * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += q[u];
+          }
+        }
+        __hip_atomic_store(shard_rows + ((int64_t)cc * ABD_TRAIN_SHARDS + shard) * ABD_NOUT + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_store(cnt_shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch on this stream)
         const unsigned int old = __hip_atomic_fetch_add(a.fin_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = old + 1u == (unsigned int)nblk ? 1 : 0;
+        flag[0] = old + 1u == (unsigned int)n_shards ? 1 : 0;
       }
     }
     __syncthreads();
     const bool last = flag[0] != 0;
     __syncthreads();
     if (!last) return;
-    double* sm = reinterpret_cast<double*>(smem);
-    double* sm_chain = sm + ABD_FIN_PARTS * ABD_NOUT;  // [CB][ABD_TRAIN_SM]
+    double* sm_chain = reinterpret_cast<double*>(smem);  // [CB][ABD_TRAIN_SM]
+    if (wave == 0 && lane < CB * ABD_NOUT) {
+      const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
+      const double* col = shard_rows + (int64_t)cc * ABD_TRAIN_SHARDS * ABD_NOUT + k;
+      double v = 0.0;
+      for (int i0 = 0; i0 < n_shards; i0 += 8) {
+        double q[8];
 #pragma unroll
-    for (int cc = 0; cc < CB; ++cc) {
-      if (a.tc[cc].action == ABD_TR_STEP) {  // (workgroup-uniform)
-        sum_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)cc * nblk * ABD_NOUT, nblk, sm, tid);
-        if (tid < ABD_NOUT) sm_chain[cc * ABD_TRAIN_SM + tid] = sm[tid];
-        __syncthreads();
+        for (int u = 0; u < 8; ++u) q[u] = i0 + u < n_shards ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += q[u];
       }
+      sm_chain[cc * ABD_TRAIN_SM + k] = v;
     }
+    __syncthreads();
     if (wave < CB && a.tc[wave].action != ABD_TR_SKIP) train_step(a, a.tc[wave], sm_chain + wave * ABD_TRAIN_SM, lane);
     if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {

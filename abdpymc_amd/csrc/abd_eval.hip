@@ -105,7 +105,7 @@ void range_split(const abd_ctx* c, int blocks, int nsub, ARGS& a, bool fused_sum
   a.rg_extra = (int32_t)(virt % n_ranges);
   a.rg_e_fin = (int32_t)e_fin;
   a.rg_n_short = (int32_t)n_short;
-  a.rg_g_magic = c->G > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)c->G - 1) / (uint64_t)c->G) : 0u;
+  a.rg_g_magic = abd_div_magic((uint32_t)c->G);
 }
 
 // Which of the context's streams can have kernels on the device at the same time?  HIP multiplexes its streams over a few
@@ -450,10 +450,15 @@ int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* 
     if (int frc = flush_pipe(c, pi)) return frc;  // (a pending fixed-order sum of an earlier plain launch on this stream)
   if (pi > 0) pp.busy = true;
   a->partials = pp.partials[0];
-  a->fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
+  a->fin_count = c->d_train_count + (size_t)pi * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE;
+  if ((int64_t)cb * (blocks + ABD_TRAIN_SHARDS) > (int64_t)c->n_slots * c->blocks_max)
+    return fail(ABD_ERR_STATE, "internal: train launch of %d x %d workgroups exceeds the partial rows", cb, blocks);
   a->prior_const = c->prior_const;
   a->xcd_remap = c->xcd_remap ? 1 : 0;
   a->service = any_fwd ? 1 : 0;
+  // the service workgroup takes a workgroup slot: a grid that fills the chip exactly gives it one of its own (the ranges are
+  // equal shares of the plane whatever their number), or the last range would only start when the first workgroup has left
+  if (a->service && any_step && blocks > 1 && blocks % c->n_cu == 0) blocks -= 1;
   a->G = c->G;
   a->N = c->N;
   a->n_lg = c->n_lg;

@@ -163,6 +163,7 @@ struct abd_ctx {
   // unchanged with 4
   bool dense_own_sum = true;
   unsigned int* d_fin_count = nullptr;  // [kMaxPipes][ABD_MAX_BATCH] zeroed counters of that sum
+  unsigned int* d_train_count = nullptr;  // [kMaxPipes][1 + ABD_TRAIN_SHARDS][ABD_TRAIN_CNT_STRIDE] zeroed counters of train launches (abd_dense.hpp)
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;

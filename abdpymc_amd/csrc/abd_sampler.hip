@@ -245,7 +245,10 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   while (dense_unit < 8 && 2 * dense_unit <= n / 4) dense_unit *= 2;
   // dense trains: units of 1, 2 or 4 chains (abd_sampler::dtrains)
   s->dtrains = trains_ok && c->dense;
-  if (s->dtrains) dense_unit = n >= 16 ? 4 : (n >= 3 ? 2 : 1);
+  // as few chains per unit as keep the units within the four hardware queues (a queue runs one kernel at a time): measured at
+  // config 3, evaluations/s seen by NUTS while all chains are at work, units of 1 / 2 / 4 chains -- 4 chains 138 k / 138 k /
+  // 102 k; 8 chains 124 k / 162 k / 161 k; 16 chains - / 149 k / 176 k
+  if (s->dtrains) dense_unit = n <= 4 ? 1 : (n <= 8 ? 2 : 4);
   s->unit = (c->dense && ((int64_t)c->G * c->N >= 500000 || s->dtrains)) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
   s->unit = env_int("ABD_SAMPLER_UNIT", s->unit);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));
@@ -423,6 +426,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
     std::vector<double> th, lp, gr;
   };
   std::vector<Unit> units((size_t)n_units);
+  const std::chrono::steady_clock::time_point t_run_begin = std::chrono::steady_clock::now();
   // host threads (see below): a power of two <= 8, so that units that share a HIP stream (u and u + 8) share their thread
   // (one thread while abd_kernel_timing is on: the event bookkeeping of enqueue_group belongs to the context, not to a unit)
   int T_all = 1;
@@ -511,6 +515,7 @@ int sampler_run_units(abd_sampler* s, int64_t n_iter, double* theta, double* sta
         o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
         o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
         o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+        o[ABD_STAT_T_DONE] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run_begin).count();
       }
     }
     // the next iteration's first leapfrogs go out BEFORE this iteration's recording is queued: the recording kernels read the
@@ -795,6 +800,7 @@ int sampler_run_trains(abd_sampler* s, int64_t n_iter, double* theta, double* st
       o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
       o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
       o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+      o[ABD_STAT_T_DONE] = std::chrono::duration<double>(clk::now() - t_begin).count();
     }
     // running sums and the draw's record: on the chain's own stream, behind its sweep and in front of the next one (they read
     // the discrete state; the point goes by value)

@@ -102,6 +102,8 @@ struct TrainArgs {
 // block (mapped host memory), read by the last workgroup of a launch in which the chain does not step.
 #define ABD_TRAIN_CB 4      // chains per unit at most (= waves of a workgroup: wave k of the last workgroup runs chain k's state machine)
 #define ABD_TRAIN_RING 64   // records per chain in mapped host memory
+#define ABD_TRAIN_SHARDS 32      // a train launch's workgroups count in in shards (abd_dense.hpp: dense_body) ...
+#define ABD_TRAIN_CNT_STRIDE 32  // ... whose counters lie 128 bytes apart: [0] the top, [(1 + s) * stride] shard s
 enum { ABD_TR_SKIP = 0, ABD_TR_STEP = 1, ABD_TR_BEGIN = 2 };  // what a launch does with a chain of its unit
 enum { ABD_PH_IDLE = 0, ABD_PH_EVAL0 = 1, ABD_PH_LEAF = 2 };  // TrainChain::phase
 struct TrainEnd {            // one end of the trajectory: point, momentum, gradient (abd_nuts.hpp: Phase)
@@ -231,6 +233,18 @@ struct EvalArgs {
   ChainPar ch[ABD_MAX_BATCH_K];
   TrainArgs train;  // dense kernel, one chain per launch (abd_sampler.hip)
 };
+
+// row / G of the dense kernel's range arithmetic (abd_dense.hpp: range_of) by a 32-bit reciprocal: magic = ceil(2^32 / G),
+// row / G = (row * magic) >> 32.  With e = magic G - 2^32 (0 <= e < G) the quotient is exact as long as row e < 2^32;
+// abd_create keeps a cohort on the dense path only if that holds for every row of its (lane group, gap) plane, n_rows
+// included (the end of the last range) -- abd_div_magic_exact; tests/native/magic_harness.cpp sweeps the boundary.
+__host__ __device__ inline uint32_t abd_div_magic(uint32_t G) { return G > 1 ? (uint32_t)((((uint64_t)1 << 32) + G - 1) / G) : 0u; }
+__host__ __device__ inline uint32_t abd_div_by_magic(uint32_t row, uint32_t magic) { return (uint32_t)(((uint64_t)row * magic) >> 32); }
+__host__ __device__ inline bool abd_div_magic_exact(uint64_t n_rows, uint32_t G) {
+  if (G <= 1) return n_rows < ((uint64_t)1 << 31);
+  const uint64_t e = (uint64_t)abd_div_magic(G) * G - ((uint64_t)1 << 32);
+  return n_rows < ((uint64_t)1 << 31) && n_rows * e < ((uint64_t)1 << 32);
+}
 
 struct double2_t {
   double x, y;

@@ -277,14 +277,35 @@ def sample_chain(model, chain: int, tune: int, draws: int, seed: int, record_det
     return res
 
 
+def record_bytes(chains: int, n_rec: int, G: int, N: int, record_deterministics: bool, record_discrete: bool) -> int:
+    """Host bytes of the per-draw arrays of a run that records ``n_rec`` draws per chain: i (int8) + ab_n_mu + ab_s_mu
+    (float64) per cell for the Deterministics, i_raw (int8) per cell + ab_s_waner (int8) per individual for the discrete state."""
+    per_draw = (G * N * 17 if record_deterministics else 0) + (G * N + N if record_discrete else 0)
+    return chains * n_rec * per_draw
+
+
+def record_budget_bytes() -> int:
+    """What the per-draw arrays of one process may take on the host (``ABD_RECORD_BUDGET_GB``, default 8 GiB)."""
+    import os
+
+    return int(float(os.environ.get("ABD_RECORD_BUDGET_GB", "8")) * 2 ** 30)
+
+
 def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
                   record_discrete: bool = True, progress: Optional[Callable[[int, int, int], None]] = None,
                   target_accept: float = 0.8, max_treedepth: int = 10, chunk: int = 50,
-                  chain_offset: int = 0, dense_metric: bool = False) -> Dict[str, np.ndarray]:
+                  chain_offset: int = 0, dense_metric: bool = False, thin: int = 1,
+                  budget_bytes: Optional[int] = None) -> Dict[str, np.ndarray]:
     """
-    All chains in lock step inside the library (``abd_sampler_*``): one launch per leapfrog for all chains, one
-    launch per Gibbs sweep for all chains.  Posterior means of the three Deterministics are accumulated on the
-    device and returned as ``mean_i``, ``mean_ab_n_mu``, ``mean_ab_s_mu``; per-draw copies only when asked for.
+    The compound step inside the library (``abd_sampler_*``): the chains advance as independent units, each at its own
+    pace (NUTS transitions as leapfrog trains on the device, the Gibbs sweep, the re-evaluation at the new state); nothing
+    a chain draws depends on the others.  Posterior means of the three Deterministics over ALL draws are accumulated on
+    the device and returned as ``mean_i``, ``mean_ab_n_mu``, ``mean_ab_s_mu`` (what the reference's downstream analysis
+    reads: survival.py:64-69, 105-114); per-draw copies of the (gap, ind) arrays only when asked for, and only of every
+    ``thin``-th draw (draws 0, thin, 2 thin, ...: ``draw_index``) -- the reference keeps every draw and thins afterwards
+    (subsample_idata.py); at BASELINE config 3 a draw is 36 MB per chain, so here it is done while sampling.  The 17
+    value variables and the sampler statistics are kept for every draw.  A run whose per-draw arrays would exceed
+    ``budget_bytes`` on the host (default ``record_budget_bytes()``) is refused with the ``thin`` that would fit.
     ``chain_offset`` is the global id of this process's first chain when chains are sharded over GPUs: local
     chain c uses the random streams of global chain ``chain_offset + c``.
     """
@@ -292,6 +313,21 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
 
     ctx = model.ctx
     G, N = model.n_gaps, model.n_inds
+    if thin < 1:
+        raise ValueError(f"thin must be >= 1, got {thin}")
+    n_rec = (draws + thin - 1) // thin
+    if record_deterministics or record_discrete:
+        budget = record_budget_bytes() if budget_bytes is None else int(budget_bytes)
+        need = record_bytes(chains, n_rec, G, N, record_deterministics, record_discrete)
+        if need > budget:
+            per_draw = need // max(n_rec, 1)
+            fit = max(1, budget // max(per_draw, 1))          # draws per chain set that fit
+            thin_fit = -(-draws // fit)
+            raise ValueError(
+                f"recording {n_rec} draws of {chains} chains x ({G}, {N}) needs {need / 2 ** 30:.1f} GiB of host arrays, over the "
+                f"budget of {budget / 2 ** 30:.1f} GiB: thin >= {thin_fit} fits (or record less: no_deterministics / "
+                f"record_discrete=False; the posterior means are returned either way; ABD_RECORD_BUDGET_GB raises the budget)")
+    chunk = max(thin, chunk - chunk % thin) if thin > 1 else chunk  # calls record iterations 0, thin, ... of THEIR range
     pt = model.initial_point()
     q0 = np.empty((chains, len(THETA_NAMES)))
     for c in range(chains):
@@ -319,18 +355,18 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
         advance(min(chunk, left))
         left -= min(chunk, left)
     thetas, stats = [], []
-    out_i_raw = np.empty((chains, draws, G, N), dtype=np.int8) if record_discrete else None
-    out_w = np.empty((chains, draws, N), dtype=np.int8) if record_discrete else None
+    out_i_raw = np.empty((chains, n_rec, G, N), dtype=np.int8) if record_discrete else None
+    out_w = np.empty((chains, n_rec, N), dtype=np.int8) if record_discrete else None
     det = None
     if record_deterministics:
-        det = dict(i=np.empty((chains, draws, G, N), dtype=np.int8), ab_n_mu=np.empty((chains, draws, G, N)),
-                   ab_s_mu=np.empty((chains, draws, G, N)))
+        det = dict(i=np.empty((chains, n_rec, G, N), dtype=np.int8), ab_n_mu=np.empty((chains, n_rec, G, N)),
+                   ab_s_mu=np.empty((chains, n_rec, G, N)))
     k = 0
     while k < draws:
         n = min(chunk, draws - k)
         if record_deterministics or record_discrete:
             # staged on the device, copied out in large blocks straight into the arrays above
-            th, st = smp.run_record(n, k, i_raw=out_i_raw, ab_s_waner=out_w, **(det or {}))
+            th, st = smp.run_record(n, k // thin, i_raw=out_i_raw, ab_s_waner=out_w, thin=thin, **(det or {}))
             n_grad += int(st["n_steps"].sum()) + n * chains
             done += n
             if progress is not None:
@@ -348,6 +384,8 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
         res["i_raw"], res["ab_s_waner"] = out_i_raw, out_w
     if det is not None:
         res.update(det)
+    if record_discrete or det is not None:
+        res["draw_index"] = np.tile(np.arange(0, draws, thin, dtype=np.int64), (chains, 1))  # which draws the (gap, ind) arrays hold
     if draws:
         means = [smp.means(c) for c in range(chains)]
         for j, name in enumerate(("mean_i", "mean_ab_n_mu", "mean_ab_s_mu")):
@@ -364,15 +402,16 @@ def sample_native(model, tune: int, draws: int, chains: int = 1, seed: int = 0, 
 def sample(model, tune: int, draws: int, chains: int = 1, seed: int = 0, record_deterministics: bool = True,
            progress: Optional[Callable[[int, int, int], None]] = None, device_gibbs: bool = True,
            native: bool = True, record_discrete: bool = True, chain_offset: int = 0,
-           dense_metric: bool = False) -> Dict[str, np.ndarray]:
-    """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes."""
+           dense_metric: bool = False, thin: int = 1, budget_bytes: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """``pm.sample(tune, draws)`` for the abd model: returns arrays with leading (chain, draw) axes (the per-draw
+    (gap, ind) arrays hold every ``thin``-th draw: ``sample_native``)."""
     if chains > model.n_chains:
         raise ValueError(f"model was built with {model.n_chains} chain slots, {chains} requested")
     if native and device_gibbs and hasattr(model.ctx, "sampler"):
         return sample_native(model, tune, draws, chains, seed, record_deterministics, record_discrete, progress,
-                             chain_offset=chain_offset, dense_metric=dense_metric)
-    if chain_offset or dense_metric:
-        raise ValueError("chain_offset / dense_metric need the native sampler")
+                             chain_offset=chain_offset, dense_metric=dense_metric, thin=thin, budget_bytes=budget_bytes)
+    if chain_offset or dense_metric or thin != 1:
+        raise ValueError("chain_offset / dense_metric / thin need the native sampler")
     per_chain = []
     for c in range(chains):
         cb = (lambda a, b, c=c: progress(c, a, b)) if progress else None

@@ -196,7 +196,7 @@ typedef struct abd_sampler_opts {
   int32_t reserved;
 } abd_sampler_opts;
 
-#define ABD_N_STATS 10
+#define ABD_N_STATS 11
 /* columns of the per-iteration statistics row */
 #define ABD_STAT_LP 0                /* joint logp after the whole compound step */
 #define ABD_STAT_TREE_DEPTH 1
@@ -208,6 +208,8 @@ typedef struct abd_sampler_opts {
 #define ABD_STAT_MAX_ENERGY_ERROR 7
 #define ABD_STAT_GIBBS_ACCEPTED 8
 #define ABD_STAT_GIBBS_PROPOSED 9
+#define ABD_STAT_T_DONE 10           /* seconds from the start of this abd_sampler_run call to the end of the chain's iteration
+                                        (host clock): chains are independent, so they finish their iterations at different times */
 
 /* chains[k] must hold a discrete state (abd_set_discrete); theta0 is n x 17, the starting points.
  * A sampler points into its context: destroy it before abd_destroy(ctx). */

@@ -35,6 +35,28 @@ def _worker(rank, world, port, q):
         assert merged["p"][:, 1].tolist() == [1.0, 11.0, 21.0] and merged["i_raw"][:, 0, 0, 0].tolist() == [0, 1, 2]
     else:
         assert merged is None
+    # a THINNED run (abdpymc-infer --thin 3 over 7 draws): the 17 scalars and the statistics keep every draw, the
+    # (gap, ind) arrays every third one (draw_index says which), the posterior means have no draw axis -- one gather
+    # per array, each with its own shape and dtype; nothing of the size of an unthinned run crosses ranks
+    draws, thin = 7, 3
+    idx = np.arange(0, draws, thin)
+    thinned = {"p": np.array([[100.0 * (first + c) + k for k in range(draws)] for c in range(counts[rank])]),
+               "stat_lp": np.array([[-1.0 * (first + c) - k for k in range(draws)] for c in range(counts[rank])]),
+               "i": np.array([np.stack([np.full((2, 3), 10 * (first + c) + k, dtype=np.int8) for k in idx]) for c in range(counts[rank])]),
+               "ab_n_mu": np.array([np.stack([np.full((2, 3), 0.5 + (first + c) + k) for k in idx]) for c in range(counts[rank])]),
+               "draw_index": np.tile(idx, (counts[rank], 1)),
+               "mean_i": np.array([np.full((2, 3), 0.25 * (first + c)) for c in range(counts[rank])])}
+    bytes_sent = sum(v.nbytes for v in thinned.values())
+    merged = gather_results(thinned, counts, dist)
+    if rank == 0:
+        assert merged["p"].shape == (3, draws) and merged["i"].shape == (3, len(idx), 2, 3) and merged["i"].dtype == np.int8
+        assert merged["draw_index"].tolist() == [idx.tolist()] * 3 and merged["mean_i"].shape == (3, 2, 3)
+        assert merged["i"][:, :, 0, 0].tolist() == [[10 * c + k for k in idx] for c in range(3)]
+        assert merged["ab_n_mu"][2, 1, 1, 2] == 0.5 + 2 + 3 and merged["stat_lp"][1, 6] == -7.0
+        # the thinned arrays are draws[::thin] of what an unthinned run would have gathered
+        assert bytes_sent < counts[rank] * draws * (2 * 3) * 9 + counts[rank] * (2 * draws + len(idx)) * 8 + counts[rank] * 6 * 8 + 1
+    else:
+        assert merged is None
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, chains, allb))

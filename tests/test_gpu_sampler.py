@@ -21,6 +21,7 @@ from oracle import abd_oracle as O
 from tests.helpers import oracle_cohort_from_synth, random_sparse_cohort
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -461,7 +462,8 @@ def test_host_threads_do_not_change_a_draw(test_td, monkeypatch):
     def compare(ref, got):
         np.testing.assert_array_equal(got[0], ref[0])
         for k in ref[1]:
-            np.testing.assert_array_equal(got[1][k], ref[1][k], err_msg=k)
+            if k != "t_done":  # (host clock)
+                np.testing.assert_array_equal(got[1][k], ref[1][k], err_msg=k)
         np.testing.assert_array_equal(got[2]["i"], ref[2]["i"])
         np.testing.assert_array_equal(got[2]["ab_s_mu"], ref[2]["ab_s_mu"])
         for c in range(C):
@@ -598,7 +600,7 @@ def test_observation_list_trains_follow_the_host_driven_chain(test_td, monkeypat
     t_a, s_a, d_a, fb_a = run("1")
     t_b, s_b, d_b, fb_b = run("1")
     assert fb_a == 0 and fb_b == 0
-    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a)
+    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a if k != "t_done")
     assert all(np.array_equal(d_a[c][0], d_b[c][0]) and np.array_equal(d_a[c][1], d_b[c][1]) for c in range(C))
     assert np.isfinite(t_a).all() and (s_a["n_steps"] >= 1).all() and s_a["n_steps"].max() > 3
     assert np.array_equal(s_a["n_steps"][:, :3], s_host["n_steps"][:, :3])
@@ -635,7 +637,7 @@ def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch):
     t_a, s_a, fb_a = run("1")
     t_b, s_b, fb_b = run("1")
     assert fb_a == 0 and fb_b == 0
-    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a)
+    assert np.array_equal(t_a, t_b) and all(np.array_equal(s_a[k], s_b[k]) for k in s_a if k != "t_done")
     assert np.isfinite(t_a).all() and (s_a["n_steps"] >= 1).all()
     # the first transitions: same trees, same points to rounding (later ones may part ways: a decision on a knife's edge)
     assert np.array_equal(s_a["n_steps"][:, :3], s_host["n_steps"][:, :3])
@@ -680,3 +682,65 @@ def test_observation_list_trains_beyond_256_gaps_report_the_oracles_logp(monkeyp
         for k in (0, 5, n_it - 1):
             lp = O.logp_dlogp(th[c, k], rec["i_raw"][c, k], rec["ab_s_waner"][c, k], coh, splits)[0]
             assert abs(lp - st["lp"][c, k]) <= 1e-9 * abs(lp), (c, k, lp, st["lp"][c, k])
+
+
+def test_thinned_recording_is_every_kth_draw_of_the_unthinned_run(test_td):
+    """--thin K (the reference thins afterwards, subsample_idata.py): recording every K-th draw does not perturb
+    the chains, the per-draw (gap, ind) arrays are bit for bit draws 0, K, 2K, ... of the unthinned run -- whatever the
+    chunking of the calls -- and the 17 scalars, the statistics and the posterior means still cover every draw."""
+    from abdpymc_amd import sampler
+    from abdpymc_amd.model import model
+
+    def run(thin, chunk):
+        m = model(test_td, splits=(14,), n_chains=3)
+        res = sampler.sample_native(m, 12, 23, chains=3, seed=4, thin=thin, chunk=chunk)
+        m.close()
+        return res
+
+    full = run(1, 50)
+    for thin, chunk in ((5, 50), (5, 7), (4, 9), (23, 50), (40, 50)):
+        got = run(thin, chunk)
+        idx = np.arange(0, 23, thin)
+        assert got["draw_index"].tolist() == [idx.tolist()] * 3
+        for name in ("i_raw", "ab_s_waner", "i", "ab_n_mu", "ab_s_mu"):
+            assert got[name].shape[1] == len(idx)
+            np.testing.assert_array_equal(got[name], full[name][:, idx], err_msg=f"{name} thin={thin} chunk={chunk}")
+        for name in ("p", "ab_n_rho", "stat_lp", "stat_n_steps", "mean_i", "mean_ab_n_mu", "mean_ab_s_mu"):
+            np.testing.assert_array_equal(got[name], full[name], err_msg=name)
+    with pytest.raises(ValueError, match="budget"):
+        m = model(test_td, splits=(14,), n_chains=3)
+        try:
+            sampler.sample_native(m, 2, 23, chains=3, budget_bytes=1000)
+        finally:
+            m.close()
+
+
+def test_cli_on_a_config3_sized_cohort_directory_stays_within_the_host_budget(tmp_path):
+    """abdpymc-infer at BASELINE sizes (missing 3): a 10 000 x 200 cohort DIRECTORY in the reference's format,
+    4 chains, --thin so that 2 draws per chain are kept.  The run must finish with a bounded host footprint (the default
+    recording of every draw is refused with the thin that fits) and write the posterior means and the thinned draws."""
+    import resource
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_cohort_dir import write_cohort_dir
+
+    d = tmp_path / "cohort"
+    write_cohort_dir(str(d), 10000, 200)
+    out = tmp_path / "post"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "abdpymc_amd.cli", "--ititers_data", str(d), "--chains", "4", "--netcdf", str(out)]
+    # (1) unthinned at this size: refused before sampling, with the thin that fits
+    r = subprocess.run(base + ["--tune", "5", "--draws", "200"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "thin >=" in r.stderr, r.stderr[-2000:]
+    # (2) thinned: runs, bounded memory
+    r = subprocess.run(base + ["--tune", "12", "--draws", "20", "--thin", "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rss_gb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 2 ** 20  # (KiB -> GiB; the largest child so far)
+    assert rss_gb < 16.0, rss_gb
+    z = np.load(str(out) + ".npz")
+    assert z["mean_i"].shape == (4, 200, 10000) and z["mean_ab_n_mu"].shape == (4, 200, 10000)
+    assert z["i"].shape == (4, 2, 200, 10000) and z["draw_index"].tolist() == [[0, 10]] * 4
+    assert z["p"].shape == (4, 20) and np.isfinite(z["stat_lp"]).all()
+    assert np.isfinite(z["mean_ab_s_mu"]).all() and 0.0 <= z["mean_i"].min() and z["mean_i"].max() <= 1.0

@@ -3,6 +3,7 @@ independent Bernoullis, and the CLI's flag set (reference abd.py:888-911)."""
 import math
 
 import numpy as np
+import pytest
 
 from abdpymc_amd.cli import build_parser
 from abdpymc_amd.sampler import DualAveraging, Nuts, binary_gibbs_sweep
@@ -68,3 +69,27 @@ def test_cli_flags_match_reference():
     a = ps.parse_args("--tune 1 --draws 2 --cores 4 --ititers_data d --split_delta --split_omicron --ignore_pcrpos --netcdf o.nc".split())
     assert (a.cores, a.ititers_data, a.netcdf) == (4, "d", "o.nc") and a.split_delta and a.split_omicron and a.ignore_pcrpos
     assert ps.prog == "abdpymc-infer"
+
+
+def test_cli_thinning_flags_and_the_record_budget():
+    """--thin / --record_every (thinned draws, posterior means always) and the host budget: at BASELINE config 3
+    the default recording of 1000 draws x 4 chains would be 144 GB of host arrays -- refused with the thin that fits, before
+    anything touches the device."""
+    from types import SimpleNamespace
+
+    from abdpymc_amd import sampler
+
+    ps = build_parser()
+    assert ps.parse_args("--tune 1 --draws 2".split()).thin == 1
+    assert ps.parse_args("--tune 1 --draws 2 --thin 50".split()).thin == 50
+    assert ps.parse_args("--tune 1 --draws 2 --record_every 7 --no_discrete".split()).thin == 7
+    G, N = 200, 10000
+    assert sampler.record_bytes(4, 1000, G, N, True, True) == 4 * 1000 * (G * N * 18 + N)  # 144 GB
+    assert sampler.record_bytes(4, 1000, G, N, False, False) == 0
+    fake = SimpleNamespace(ctx=None, n_gaps=G, n_inds=N)  # the check comes before the context is used
+    with pytest.raises(ValueError, match=r"thin >= 1[78]"):
+        sampler.sample_native(fake, 100, 1000, chains=4, budget_bytes=8 * 2 ** 30)
+    with pytest.raises(ValueError, match="thin must be >= 1"):
+        sampler.sample_native(fake, 100, 1000, chains=4, thin=0)
+    # thin 50 at --draws 200 --chains 4: 4 draws per chain = 0.58 GB
+    assert sampler.record_bytes(4, 4, G, N, True, True) < 2 ** 30

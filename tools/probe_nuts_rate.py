@@ -41,13 +41,19 @@ for c in range(C):
     ctx.set_discrete(c, *states[c])
 ta = float(os.environ.get("ABD_PROBE_TARGET_ACCEPT", "0.8"))  # closer to 1: smaller steps, longer trees
 gibbs = os.environ.get("ABD_PROBE_GIBBS", "0") == "1"  # 1: the compound step (sweep after every transition)
-smp = ctx.sampler(np.arange(C), th0, tune=10 ** 6, seed=3, gibbs=gibbs, target_accept=ta)
-smp.run(60 if gibbs else 15)  # step size settles (and, with the sweep, the discrete state leaves its random start)
+tune = int(os.environ.get("ABD_PROBE_TUNE", "100"))  # adaptation ends after this many iterations: the timed ones run at a fixed step size
+smp = ctx.sampler(np.arange(C), th0, tune=tune, seed=3, gibbs=gibbs, target_accept=ta)
+smp.run(max(tune, 60 if gibbs else 15))  # step size settles (and, with the sweep, the discrete state leaves its random start)
 t0 = time.perf_counter()
 _, st = smp.run(iters)
 dt = time.perf_counter() - t0
 evals = float(st["n_steps"].sum())
-print(f"{cfg} chains={C} unit={os.environ.get('ABD_SAMPLER_UNIT', 'auto')}: {evals / dt:,.0f} evals/s as seen by NUTS "
-      f"({evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains, "
-      f"{dt / (evals / C) * 1e6:.1f} us per leapfrog of a chain); wait fall-backs {ctx.wait_fallbacks}")
+# chains are independent and finish at different times: the rate while ALL of them are still at work
+t_first = float(st["t_done"][:, -1].min())
+in_window = float(st["n_steps"][st["t_done"] <= t_first].sum())
+per_chain = [int(x) for x in st["n_steps"].sum(axis=1)]
+print(f"{cfg} chains={C} unit={os.environ.get('ABD_SAMPLER_UNIT', 'auto')}: {evals / dt:,.0f} evals/s as seen by NUTS over the call, "
+      f"{in_window / t_first:,.0f} while all chains are at work (the first one finishes after {t_first / dt * 100:.0f} % of the call; leapfrogs per chain {per_chain}); "
+      f"{evals / iters / C:.1f} leapfrogs per iteration and chain, {dt / iters * 1e3:.2f} ms of wall time per iteration of all chains, "
+      f"{dt / (evals / C) * 1e6:.1f} us per leapfrog of a chain; wait fall-backs {ctx.wait_fallbacks}")
 smp.close()

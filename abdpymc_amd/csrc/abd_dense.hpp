@@ -818,9 +818,9 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
   if (!own_sum) return;
 
   // ---- own fixed-order sum: the workgroup that counts in last sums the partial rows itself instead of a second launch.
-  // Hand-off (MI355X guide, "valid forms"): every partial row of this workgroup was stored write-through
-  // (sc1) by wave 0 (CB x 16 <= 64 lanes), wave 0 drains its stores (s_waitcnt vmcnt(0)) and then one lane per chain counts
-  // in with a returning agent-scope add; the workgroup whose add came last re-reads the rows with sc1 loads behind a barrier
+  // Hand-off (abd_device.hpp: handoff_count_in): every partial row of this workgroup was stored write-through (sc1) by wave 0
+  // (CB x 16 <= 64 lanes) in front of a workgroup barrier; one lane per counter counts in with a returning agent-scope
+  // acq_rel add; the workgroup whose add came last re-reads the rows with sc1 loads behind another barrier
   int* flag = reinterpret_cast<int*>(red);  // the block reduction is done with: [CB] flags
   __syncthreads();
   if constexpr (TRAINK) {
@@ -836,9 +836,9 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     unsigned int* cnt_shard = a.fin_count + (1 + shard) * ABD_TRAIN_CNT_STRIDE;
     double* shard_rows = a.partials + (int64_t)CB * nblk * ABD_NOUT;  // [CB][ABD_TRAIN_SHARDS][ABD_NOUT]
     if (wave == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      handoff_drain_stores();
       if (lane == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(cnt_shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = handoff_count_in(cnt_shard);
         flag[0] = old + 1u == (unsigned int)n_in_shard ? 1 : 0;
       }
     }
@@ -846,6 +846,7 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     const bool shard_last = flag[0] != 0;
     __syncthreads();
     if (!shard_last) return;
+    handoff_acquire();
     if (wave == 0) {
       if (lane < CB * ABD_NOUT) {
         const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
@@ -863,10 +864,10 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
         }
         __hip_atomic_store(shard_rows + ((int64_t)cc * ABD_TRAIN_SHARDS + shard) * ABD_NOUT + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      handoff_drain_stores();
       if (lane == 0) {
         __hip_atomic_store(cnt_shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch on this stream)
-        const unsigned int old = __hip_atomic_fetch_add(a.fin_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = handoff_count_in(a.fin_count);
         flag[0] = old + 1u == (unsigned int)n_shards ? 1 : 0;
       }
     }
@@ -874,6 +875,7 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     const bool last = flag[0] != 0;
     __syncthreads();
     if (!last) return;
+    handoff_acquire();
     double* sm_chain = reinterpret_cast<double*>(smem);  // [CB][ABD_TRAIN_SM]
     if (wave == 0 && lane < CB * ABD_NOUT) {
       const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
@@ -893,9 +895,9 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     if (wave == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      handoff_drain_stores();
       if (lane < CB) {
-        const unsigned int old = __hip_atomic_fetch_add(a.fin_count + cbase + lane, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = handoff_count_in(a.fin_count + cbase + lane);
         flag[lane] = old + 1u == gridDim.x ? 1 : 0;
       }
     }
@@ -907,6 +909,7 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
 #pragma unroll
     for (int cc = 0; cc < CB; ++cc) {
       if (last[cc]) {
+        handoff_acquire();
         finalize_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)(cbase + cc) * gridDim.x * ABD_NOUT, (int)gridDim.x,
                                            a.fin_out + (int64_t)(cbase + cc) * ABD_NOUT, reinterpret_cast<double*>(smem), tid, a.fin_tag);
         if (tid == 0) __hip_atomic_store(a.fin_count + cbase + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

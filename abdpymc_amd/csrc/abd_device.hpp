@@ -11,6 +11,48 @@ __device__ __forceinline__ double to_vgpr(double x) {
   return x;
 }
 
+// A workgroup counts in at an agent-scope counter on behalf of the rows it has stored (the stores of all its waves lie behind
+// a workgroup barrier the caller has passed; the rows themselves are write-through (sc1) stores, re-read with sc1 loads).
+//   ABD_HANDOFF_FORMAL = 0 (the product): the form the MI355X guide lists as valid and measured on gfx950 -- the storing wave
+//     drains its stores (s_waitcnt vmcnt(0)), then a relaxed returning agent-scope add; the workgroup whose add came last
+//     re-reads the rows with sc1 loads behind a barrier.  It rests on gfx9's store acknowledgements (a write-through store
+//     is acknowledged once it is visible at agent scope), not on the HIP memory model: gfx950 builds only (checked below).
+//   ABD_HANDOFF_FORMAL = 1: the counting add is acq_rel at agent scope (release/acquire as the memory model defines them, no
+//     inline assembly); = 2: release with the add, acquire only in the workgroup that turns out to be last.
+//     Measured (round 4, profiles/README.md: g_handoff_ab.txt): both cost far more than the 3 % that would have been accepted --
+//     every workgroup's release is a buffer_wbl2 sc1 of its XCD's L2 -- config 3, evaluations/s seen by NUTS while all four
+//     chains are at work: 141 k (0) / 48 k (1) / 42 k (2); default cohort 285 k / 221 k / 246 k.  Hence 0.
+#ifndef ABD_HANDOFF_FORMAL
+#define ABD_HANDOFF_FORMAL 0
+#endif
+#if ABD_HANDOFF_FORMAL == 0 && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the drained-stores hand-off (ABD_HANDOFF_FORMAL=0) is validated on gfx950 only: build other targets with -DABD_HANDOFF_FORMAL=1"
+#endif
+__device__ __forceinline__ unsigned int handoff_count_in(unsigned int* cnt) {
+#if ABD_HANDOFF_FORMAL == 1
+  return __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#elif ABD_HANDOFF_FORMAL == 2
+  return __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// the workgroup whose add came last, before it reads the other workgroups' rows
+__device__ __forceinline__ void handoff_acquire() {
+#if ABD_HANDOFF_FORMAL == 2
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+// the storing wave, all lanes, between its stores and the lane that counts in for them
+__device__ __forceinline__ void handoff_drain_stores() {
+#if ABD_HANDOFF_FORMAL
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the lanes' stores happen before the counting lane's release
+  __builtin_amdgcn_wave_barrier();
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

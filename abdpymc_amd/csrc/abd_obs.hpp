@@ -191,9 +191,9 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
   int* flag = reinterpret_cast<int*>(red + ABD_WAVES_PER_BLOCK * 8);
   __syncthreads();
   if (wave == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    handoff_drain_stores();
     if (lane == 0) {
-      const unsigned int old = __hip_atomic_fetch_add(a.fin_count + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int old = handoff_count_in(a.fin_count + blockIdx.y);
       flag[0] = old + 1u == gridDim.x ? 1 : 0;
     }
   }
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
   const bool last = flag[0] != 0;  // workgroup-uniform; read before the sum's scratch overwrites the flag
   __syncthreads();
   if (!last) return;
+  handoff_acquire();
   const double* rows = a.partials + (int64_t)blockIdx.y * gridDim.x * ABD_NOUT;
   if (GRAD && a.train.enabled) {
     sum_chain_coherent<ABD_BLOCK>(rows, (int)gridDim.x, reinterpret_cast<double*>(smem), tid);

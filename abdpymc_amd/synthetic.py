@@ -126,7 +126,7 @@ def make_cohort(n_inds: int, n_gaps: int, seed: int = SEED) -> SyntheticCohort:
 
     def od(mu):
         x = rng.choice(np.array([0.0, 2.0, 4.0]), size=G * N)
-        a = mu[idx_gap, idx_ind]
+        a = np.ascontiguousarray(mu.T).ravel()  # = mu[idx_gap, idx_ind]: observation k = j * G + g reads mu[g, j]
         y = d / (1.0 + np.exp(-b * (x - a))) + sd * rng.standard_normal(G * N)
         return x, y
 

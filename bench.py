@@ -88,6 +88,110 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
+def build_context(cfg, device, rank=0, splits=None):
+    """(ctx, cohort, splits, states, G, N, C) of a BASELINE configuration on `device`: panels resident, every chain slot holding its
+    own random discrete state."""
+    from types import SimpleNamespace
+
+    from abdpymc_amd import synthetic
+    from abdpymc_amd._native import Context
+
+    G, N, C = cfg["n_gaps"], cfg["n_inds"], cfg["chains"]
+    if cfg.get("cohort") == "default":
+        # BASELINE config 1: the reference's own cohort (data/cohort_data, packed as tests/golden/default_cohort.npz) with the
+        # splits abdpymc-infer --split_delta --split_omicron gives it (abd.py:204-221)
+        z = np.load(os.path.join(ROOT, "tests", "golden", "default_cohort.npz"))
+        m_s = z["is_s"]
+        cols = lambda m: (z["elapsed_months"][m], z["individual_i"][m], z["log_dilution"][m], z["od"][m])  # noqa: E731
+        sc = SimpleNamespace(s_obs=cols(m_s), n_obs=cols(~m_s), vacs=z["vacs"], pcrpos=z["pcrpos"])
+        assert int(z["elapsed_months"].max()) + 1 == G and int(z["individual_i"].max()) + 1 == N
+        splits = splits or (14, 20)
+    else:
+        sc = synthetic.make_cohort(N, G)
+    ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=splits, n_chains=C, storage=cfg["storage"], device=device)
+    states = []
+    for c in range(C):
+        i_raw, w = synthetic.make_chain_state(N, G, rank * C + c)  # (global chain id)
+        ctx.set_discrete(c, i_raw, w)
+        states.append((i_raw, w))
+    return ctx, sc, splits, states, G, N, C
+
+
+def nuts_rates(ctx, chains, theta0, tune=100, iters=200, seed=3):
+    """The rate a sampling run gets: leapfrogs (= logp+grad evaluations) per wall second inside abd_sampler_run, NUTS only.
+    `tune` adapting iterations (untimed), then `iters` timed ones at the adapted step sizes.  Chains are independent and
+    their trees differ, so they finish the call at different times: `value` is over the whole call (which ends with the
+    slowest chain), `all_chains_at_work` over the stretch in which none has finished yet (from the per-iteration
+    completion times the sampler reports)."""
+    C = len(chains)
+    smp = ctx.sampler(chains, theta0, tune=tune, seed=seed, gibbs=False)
+    smp.run(tune)
+    t5 = time.perf_counter()
+    _, st = smp.run(iters)
+    t_n = time.perf_counter() - t5
+    smp.close()
+    n_lf = float(st["n_steps"].sum())
+    t_first = float(st["t_done"][:, -1].min())
+    in_window = float(st["n_steps"][st["t_done"] <= t_first].sum())
+    return dict(value=round(n_lf / t_n, 1), all_chains_at_work=round(in_window / max(t_first, 1e-9), 1),
+                first_chain_done_at=round(t_first / t_n, 3), chains=C, iterations=iters, tune=tune, seconds=round(t_n, 3),
+                leapfrogs_per_iteration_and_chain=round(n_lf / iters / C, 1),
+                leapfrogs_per_chain=[int(x) for x in np.asarray(st["n_steps"]).sum(axis=1)],
+                us_per_leapfrog_of_a_chain=round(t_n / max(n_lf / C, 1.0) * 1e6, 2))
+
+
+def other_config(key, device, K=20, W=5, min_seconds=0.15):
+    """A bounded pass over another single-GPU BASELINE configuration: the stream-ordered rate of K-step regions (median),
+    the device time per launch of that shape (HIP events, abd_kernel_timing mode 2) against the HBM roof, the waiting caller's
+    rate, and the rate NUTS sees."""
+    from abdpymc_amd import synthetic
+
+    t_cfg = time.perf_counter()
+    cfg = dict(CONFIGS[key])
+    ctx, sc, splits, states, G, N, C = build_context(cfg, device)
+    chains = np.arange(C, dtype=np.int32)
+    thetas = np.empty((K + W, C, 17))
+    for c in range(C):
+        thetas[:, c, :] = synthetic.make_thetas(G, K + W, c)
+    lp, g = np.empty((K, C)), np.empty((K, C, 17))
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.05:
+        ctx.logp_dlogp_many(chains, thetas[:W], lp[:W], g[:W])
+    ctx.kernel_timing(2)
+    ctx.kernel_time(reset=True)
+    times, per_launch = [], []
+    t_r = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_r < min_seconds and len(times) < 200):
+        ctx.wait()
+        ctx.kernel_time(reset=True)
+        t0 = time.perf_counter()
+        ctx.logp_dlogp_many(chains, thetas[W:], lp, g)
+        times.append(time.perf_counter() - t0)
+        ms_r, n_r = ctx.kernel_time(reset=True)
+        per_launch.append(ms_r / max(n_r, 1))
+    ctx.kernel_timing(0)
+    if not np.all(np.isfinite(lp)):
+        raise SystemExit(f"non-finite logp in config {key}")
+    el = float(np.median(times))
+    k_us = float(np.median(per_launch)) * 1e3
+    alg = ctx.algorithmic_bytes(C)
+    ach = alg / (k_us * 1e-6) / 1e9
+    ks = min(K, 20)
+    t1 = time.perf_counter()
+    for k in range(W, W + ks):
+        ctx.logp_dlogp_batch(chains, thetas[k])
+    sync = ks * C / (time.perf_counter() - t1)
+    nuts = nuts_rates(ctx, chains, thetas[W], tune=60, iters=60)
+    out = dict(workload=cfg["name"], value=round(K * C / el, 1), ms_per_step=round(el / K * 1e3, 5), steps=K, repeats=len(times),
+               kernel_us=round(k_us, 3), roofline=dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, frac=round(ach / HBM_PEAK_GBS, 4),
+                                                       algorithmic_bytes_per_launch=int(alg), evals_per_launch=C,
+                                                       kernel="abd_dense_kernel" if ctx.is_dense else "abd_obs_kernel"),
+               sync_evals_per_s=round(sync, 1), nuts_evals_per_s=nuts["value"], nuts=nuts, wait_fallbacks=int(ctx.wait_fallbacks))
+    ctx.close()
+    out["seconds"] = round(time.perf_counter() - t_cfg, 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +202,8 @@ def main():
     ap.add_argument("--splits", default="", help="comma separated gap indexes, e.g. 100 or 66,133")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true", help="skip the sweep / compound-step / NUTS section (A/B runs of the kernels: tools/ab_bench.sh)")
-    ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bounded passes over BASELINE configs 5, 1 and 2 (`other_configs`)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step region until this much timed work")
     ap.add_argument("--max-repeats", type=int, default=400)
     args = ap.parse_args()
@@ -143,30 +248,11 @@ def main():
     K, W = args.steps, args.warmup
 
     default_cohort = cfg.get("cohort") == "default"
-    if default_cohort:
-        # BASELINE config 1: the reference's own cohort (data/cohort_data, packed as tests/golden/default_cohort.npz) with the
-        # splits abdpymc-infer --split_delta --split_omicron gives it (abd.py:204-221)
-        from types import SimpleNamespace
-
-        z = np.load(os.path.join(ROOT, "tests", "golden", "default_cohort.npz"))
-        m_s = z["is_s"]
-        cols = lambda m: (z["elapsed_months"][m], z["individual_i"][m], z["log_dilution"][m], z["od"][m])  # noqa: E731
-        sc = SimpleNamespace(s_obs=cols(m_s), n_obs=cols(~m_s), vacs=z["vacs"], pcrpos=z["pcrpos"])
-        assert int(z["elapsed_months"].max()) + 1 == G and int(z["individual_i"].max()) + 1 == N
-        splits = splits or (14, 20)
-    else:
-        sc = synthetic.make_cohort(N, G)
-    ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, splits=splits, n_chains=C,
-                  storage=cfg["storage"], device=device)
+    ctx, sc, splits, states, G, N, C = build_context(cfg, device, rank, splits)
     chains = np.arange(C, dtype=np.int32)
     thetas = np.empty((K + W, C, 17))
-    states = []
     for c in range(C):
-        gchain = rank * C + c  # global chain id
-        i_raw, w = synthetic.make_chain_state(N, G, gchain)
-        ctx.set_discrete(c, i_raw, w)
-        states.append((i_raw, w))
-        thetas[:, c, :] = synthetic.make_thetas(G, K + W, gchain)
+        thetas[:, c, :] = synthetic.make_thetas(G, K + W, rank * C + c)
 
     def barrier():
         if dist is not None:
@@ -393,7 +479,7 @@ def main():
                    b0_reference_algorithm=b0)
 
     # ---- the rate a sampling run gets, and the compound step around it (rank 0, N=1 only) ----
-    compound, nuts = None, None
+    compound, nuts, nuts_own = None, None, None
     if rank == 0 and world == 1 and not args.no_sampler:
         def sweep_ms(theta_rows, n=5):
             ts = []
@@ -417,47 +503,47 @@ def main():
             sweep_conv = sweep_ms(np.tile(synthetic.truth_theta(G), (C, 1)))
         for c in range(C):
             ctx.set_discrete(c, *states[c])
-        # the compound step, first iterations from the bench's chain states (step size still adapting: short trees)
-        iters = 12
-        smp = ctx.sampler(chains, thetas[W], tune=iters, seed=1)
+        # the compound step as abdpymc-infer runs it (NUTS transition, sweep, re-evaluation; nothing recorded): 200 iterations of
+        # every chain from the bench's random chain states, the first 100 adapting
+        n_cs = 200
+        smp = ctx.sampler(chains, thetas[W], tune=100, seed=1)
         t3 = time.perf_counter()
-        _, st = smp.run(iters)
+        _, st = smp.run(n_cs)
         dt3 = time.perf_counter() - t3
         smp.close()
-        compound = dict(chain_iterations_per_s=round(iters * C / dt3, 1), iterations=iters,
-                        leapfrogs_per_iteration=round(float(st["n_steps"].mean()), 1), gibbs_sweep_ms=round(sweep_random, 3),
+        compound = dict(chain_iterations_per_s=round(n_cs * C / dt3, 1), iterations=n_cs, seconds=round(dt3, 3),
+                        leapfrogs_per_iteration=round(float(st["n_steps"].mean()), 1),
+                        gibbs_acceptances_per_sweep=round(float(st["gibbs_accepted"].mean()), 1),
+                        gibbs_sweep_ms=round(sweep_random, 3),
                         gibbs_sweep_ms_converged_state=None if sweep_conv is None else round(sweep_conv, 3),
-                        note="gibbs_sweep_ms: one sweep of all chains (median of 5) starting from the bench's fresh random discrete state, "
-                             f"before any sampler run ({C} chains x {G * N + N} binary dims); _converged_state: the same on the simulation's own "
-                             "infections and parameters; chain_iterations_per_s: abd_sampler_run, first iterations (step size still adapting)")
-        # NUTS as the native sampler runs it (no sweep): step size settles for 15 iterations, then one call of 300 iterations.
-        # Every chain samples the SAME target here (chain 0's discrete state; own start, own random stream), as the chains
-        # of a real run do once they have converged: with a different random discrete state per chain and no sweep the step
-        # sizes -- and with them the tree lengths -- differ several-fold between chains, and the call, which ends with its
-        # longest chain, measures that imbalance rather than the rate (profiles/r03: 89-109 k against 122-133 k)
+                        note="chain_iterations_per_s: abd_sampler_run, NUTS + sweep + re-evaluation, 200 iterations of every chain from the "
+                             "bench's fresh random chain states (100 adapting), nothing recorded; gibbs_sweep_ms: one sweep of all chains "
+                             f"(median of 5) starting from that fresh random discrete state, before any sampler run ({C} chains x {G * N + N} "
+                             "binary dims); _converged_state: the same on the simulation's own infections and parameters")
+        # NUTS as the native sampler runs it (no sweep): 100 adapting iterations, then one call of 200 at the adapted step sizes.
+        # `nuts`: every chain samples the SAME target (chain 0's discrete state; own start, own random stream), as the chains of
+        # a real run do once they have converged; `nuts_own_states`: every chain on its own random discrete state -- without a
+        # sweep those are four different targets whose step sizes, and with them the tree lengths, differ several-fold
         for c in range(C):
             ctx.set_discrete(c, *states[0])
-        smp = ctx.sampler(chains, thetas[W], tune=10 ** 6, seed=3, gibbs=False)
-        smp.run(15)
-        n_it = 300  # one call: a run ends with its slowest chain, so short calls would time their idle tails
-        t5 = time.perf_counter()
-        _, st = smp.run(n_it)
-        t_n = time.perf_counter() - t5
-        n_lf = float(st["n_steps"].sum())
-        smp.close()
-        nuts = dict(value=round(n_lf / t_n, 1), chains=C, iterations=n_it, seconds=round(t_n, 3),
-                    leapfrogs_per_iteration_and_chain=round(n_lf / n_it / C, 1),
-                    leapfrogs_per_chain=[int(x) for x in np.asarray(st["n_steps"]).reshape(C, -1).sum(axis=1)],
-                    us_per_leapfrog_of_a_chain=round(t_n / (n_lf / C) * 1e6, 2),
-                    note="leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only, every chain on "
-                         "the same discrete state (chain 0's); dense "
-                         "cohorts with one chain per unit run leapfrog trains (every launch leaves the next point of the half for the "
-                         "launch queued behind it); each chain reads the OD panels for itself, so the rate is bound by "
-                         "bytes per evaluation, not by the batched kernel's instruction roof.  Chains are independent: the call "
-                         "ends with the chain that had the most leapfrogs (leapfrogs_per_chain), the others idle behind it -- "
-                         "leapfrogs_per_chain shows the spread")
+        nuts = nuts_rates(ctx, chains, thetas[W])
         for c in range(C):
             ctx.set_discrete(c, *states[c])
+        nuts_own = nuts_rates(ctx, chains, thetas[W])
+        note = ("leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only; dense cohorts "
+                "run leapfrog trains (abd_train.hpp: a launch takes the chains of its unit one leapfrog further and leaves the next "
+                "points for the launch queued behind it).  Chains are independent: `value` is over the whole call, which ends with "
+                "the chain that had the most leapfrogs (leapfrogs_per_chain), `all_chains_at_work` over the stretch before the "
+                "first chain finishes")
+        nuts["note"] = note + "; every chain on the same discrete state (chain 0's)"
+        nuts_own["note"] = note + "; every chain on its own random discrete state"
+
+    wait_fallbacks, device_name = int(ctx.wait_fallbacks), ctx.device_name
+    other = None
+    if rank == 0 and world == 1 and args.config == "c3" and not args.no_other_configs and not args.no_sampler:
+        ctx.close()
+        ctx = None
+        other = {key: other_config(key, device) for key in ("c5", "c1", "c2")}
 
     if rank == 0:
         line = {
@@ -487,18 +573,23 @@ def main():
             "sync_evals_per_s": round(sync_rate, 1),
             "nuts_evals_per_s": None if nuts is None else nuts["value"],
             "nuts": nuts,
+            "nuts_own_states": nuts_own,
             "compound_step": compound,
-            "wait_fallbacks": int(ctx.wait_fallbacks),
+            "sampler_c3" if args.config == "c3" else "sampler": None if compound is None else
+            {k: compound[k] for k in ("chain_iterations_per_s", "iterations", "seconds", "leapfrogs_per_iteration", "gibbs_acceptances_per_sweep")},
+            "other_configs": other,
+            "wait_fallbacks": wait_fallbacks,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
             "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                 "device_of_rank0": device},
-            "device": ctx.device_name,
+            "device": device_name,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

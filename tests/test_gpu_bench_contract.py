@@ -55,6 +55,22 @@ def test_bench_line_has_the_contract_fields():
     assert d["nuts_evals_per_s"] == nu["value"] > 1e4 and nu["chains"] == 4
     assert nu["iterations"] >= 200 or nu["seconds"] >= 1.0
     assert d["nuts_evals_per_s"] < d["value"]
+    # ... over the whole call and while all chains are still at work, on one shared and on four own discrete states
+    own = d["nuts_own_states"]
+    for x in (nu, own):
+        assert x["value"] <= x["all_chains_at_work"] * 1.02 and 0 < x["first_chain_done_at"] <= 1.0 and len(x["leapfrogs_per_chain"]) == 4
+    assert "own random discrete state" in own["note"] and "same discrete state" in nu["note"]
+    # the compound step of abdpymc-infer at config 3: 4 chains x 200 iterations
+    sc3 = d["sampler_c3"]
+    assert sc3["iterations"] == 200 and sc3["chain_iterations_per_s"] > 100 and sc3["leapfrogs_per_iteration"] > 3
+    # every other single-GPU BASELINE configuration in the driver's own line (bounded passes)
+    oc = d["other_configs"]
+    assert sorted(oc) == ["c1", "c2", "c5"]
+    for key, o in oc.items():
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and o["kernel_us"] > 0 and o["nuts_evals_per_s"] > 0 and o["wait_fallbacks"] == 0, key
+        assert abs(o["roofline"]["frac"] - o["roofline"]["achieved"] / 8000.0) < 1e-3 and o["kernel_us"] <= o["ms_per_step"] * 1e3 * 1.05, key
+    assert oc["c5"]["workload"].startswith("synthetic 100000 ind") and oc["c1"]["workload"].startswith("reference default cohort")
+    assert oc["c5"]["roofline"]["frac"] > 0.3
     # sweep times on states the note names: fresh random state first, the converged one beside it
     cs = d["compound_step"]
     assert cs["gibbs_sweep_ms"] > cs["gibbs_sweep_ms_converged_state"] > 0 and "fresh random" in cs["note"]

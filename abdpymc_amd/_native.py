@@ -117,6 +117,7 @@ SYMBOLS = {
     "abd_sampler_destroy": (None, [_P]),
     "abd_sampler_run": (C.c_int, [_P, C.c_int64, _D, _D]),
     "abd_sampler_run_record": (C.c_int, [_P, C.c_int64, _D, _D, C.POINTER(_Record)]),
+    "abd_sampler_set_adaptation": (C.c_int, [_P, C.c_int32, _D, C.c_double]),
     "abd_sampler_means": (C.c_int, [_P, C.c_int32, _D, _D, _D, C.POINTER(C.c_int64)]),
     "abd_sampler_adaptation": (C.c_int, [_P, C.c_int32, _D, _D, _D]),
     "abd_theta_prior": (C.c_int, [_P, _D, _D, _D]),
@@ -628,6 +629,13 @@ class NativeSampler:
         eps = C.c_double()
         _check(self._lib, self._lib.abd_sampler_adaptation(self._h, int(k), _ptr(inv_mass, C.c_double), C.byref(eps), None))
         return inv_mass, eps.value
+
+    def set_adaptation(self, k: int, inv_mass=None, step_size: float = 0.0):
+        """Install a diagonal M^-1 and / or a step size for the k-th chain (between two runs)."""
+        im = None if inv_mass is None else np.ascontiguousarray(inv_mass, dtype=np.float64)
+        if im is not None and im.shape != (N_THETA,):
+            raise ValueError(f"inv_mass must have {N_THETA} entries")
+        _check(self._lib, self._lib.abd_sampler_set_adaptation(self._h, int(k), None if im is None else _ptr(im, C.c_double), float(step_size)))
 
     def metric(self, k: int) -> np.ndarray:
         """Full M^-1 (17 x 17) of the k-th chain."""

@@ -1071,4 +1071,21 @@ int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* 
   return ABD_OK;
 }
 
+int abd_sampler_set_adaptation(abd_sampler* s, int32_t k, const double* inv_mass, double step_size) {
+  if (!s) return fail(ABD_ERR_ARG, "sampler is NULL");
+  if (k < 0 || k >= s->n) return fail(ABD_ERR_ARG, "k=%d outside [0, %d)", k, s->n);
+  abdnuts::Nuts& nu = s->ch[(size_t)k].nuts;
+  if (nu.dense) return fail(ABD_ERR_STATE, "chain %d runs a dense metric", k);
+  if (inv_mass) {
+    for (int d = 0; d < ABD_N_THETA; ++d)
+      if (!(inv_mass[d] > 0.0) || !std::isfinite(inv_mass[d])) return fail(ABD_ERR_ARG, "inv_mass[%d]=%g is not a positive finite number", d, inv_mass[d]);
+    std::memcpy(nu.inv_mass, inv_mass, sizeof(double) * ABD_N_THETA);
+  }
+  if (step_size > 0.0) {
+    if (!std::isfinite(step_size)) return fail(ABD_ERR_ARG, "step_size is not finite");
+    nu.eps = step_size;
+  }
+  return ABD_OK;
+}
+
 }  // extern "C"

@@ -117,15 +117,22 @@ def build_context(cfg, device, rank=0, splits=None):
     return ctx, sc, splits, states, G, N, C
 
 
-def nuts_rates(ctx, chains, theta0, tune=100, iters=200, seed=3):
+def nuts_rates(ctx, chains, theta0, tune=100, iters=200, seed=3, pooled=False):
     """The rate a sampling run gets: leapfrogs (= logp+grad evaluations) per wall second inside abd_sampler_run, NUTS only.
     `tune` adapting iterations (untimed), then `iters` timed ones at the adapted step sizes.  Chains are independent and
     their trees differ, so they finish the call at different times: `value` is over the whole call (which ends with the
     slowest chain), `all_chains_at_work` over the stretch in which none has finished yet (from the per-iteration
-    completion times the sampler reports)."""
+    completion times the sampler reports).  pooled: after tuning every chain gets the SAME step size and metric (the
+    geometric mean over the chains), so that the chains' trees are equally long on average."""
     C = len(chains)
     smp = ctx.sampler(chains, theta0, tune=tune, seed=seed, gibbs=False)
     smp.run(tune)
+    if pooled:
+        ad = [smp.adaptation(k) for k in range(C)]
+        im = np.exp(np.mean([np.log(a[0]) for a in ad], axis=0))
+        eps = float(np.exp(np.mean([np.log(a[1]) for a in ad])))
+        for k in range(C):
+            smp.set_adaptation(k, im, eps)
     t5 = time.perf_counter()
     _, st = smp.run(iters)
     t_n = time.perf_counter() - t5
@@ -479,7 +486,7 @@ def main():
                    b0_reference_algorithm=b0)
 
     # ---- the rate a sampling run gets, and the compound step around it (rank 0, N=1 only) ----
-    compound, nuts, nuts_own = None, None, None
+    compound, nuts, nuts_own, nuts_bal = None, None, None, None
     if rank == 0 and world == 1 and not args.no_sampler:
         def sweep_ms(theta_rows, n=5):
             ts = []
@@ -530,6 +537,11 @@ def main():
         for c in range(C):
             ctx.set_discrete(c, *states[c])
         nuts_own = nuts_rates(ctx, chains, thetas[W])
+        for c in range(C):
+            ctx.set_discrete(c, *states[0])
+        nuts_bal = nuts_rates(ctx, chains, thetas[W], pooled=True)
+        for c in range(C):
+            ctx.set_discrete(c, *states[c])
         note = ("leapfrogs (= logp+grad evaluations) of all chains per wall second inside abd_sampler_run, NUTS only; dense cohorts "
                 "run leapfrog trains (abd_train.hpp: a launch takes the chains of its unit one leapfrog further and leaves the next "
                 "points for the launch queued behind it).  Chains are independent: `value` is over the whole call, which ends with "
@@ -537,6 +549,8 @@ def main():
                 "first chain finishes")
         nuts["note"] = note + "; every chain on the same discrete state (chain 0's)"
         nuts_own["note"] = note + "; every chain on its own random discrete state"
+        nuts_bal["note"] = note + ("; every chain on the same discrete state and, after tuning, on the same step size and metric (pooled "
+                                   "over the chains: abd_sampler_set_adaptation), so that no chain idles behind another for long")
 
     wait_fallbacks, device_name = int(ctx.wait_fallbacks), ctx.device_name
     other = None
@@ -574,6 +588,7 @@ def main():
             "nuts_evals_per_s": None if nuts is None else nuts["value"],
             "nuts": nuts,
             "nuts_own_states": nuts_own,
+            "nuts_balanced": nuts_bal,
             "compound_step": compound,
             "sampler_c3" if args.config == "c3" else "sampler": None if compound is None else
             {k: compound[k] for k in ("chain_iterations_per_s", "iterations", "seconds", "leapfrogs_per_iteration", "gibbs_acceptances_per_sweep")},

@@ -245,6 +245,10 @@ int abd_sampler_means(abd_sampler* s, int32_t k, double* i_mean, double* ab_n_mu
 /* Current diagonal of M^-1 (17) and step size of chain k; `metric` (17 x 17, may be NULL) receives the full
  * M^-1 (the diagonal matrix when the metric is diagonal). */
 int abd_sampler_adaptation(abd_sampler* s, int32_t k, double* inv_mass, double* step_size, double* metric);
+/* Install a diagonal M^-1 (17 entries, all > 0; NULL keeps the chain's) and / or a step size (<= 0 keeps the chain's) for chain
+ * k between two abd_sampler_run calls, e.g. one adaptation pooled over the chains (PyMC: pm.sample(step=pm.NUTS(scaling=...,
+ * step_scale=...))).  During iterations < tune the chain goes on adapting from there. */
+int abd_sampler_set_adaptation(abd_sampler* s, int32_t k, const double* inv_mass, double step_size);
 
 /* ---------------------------------------------------------------------------------------------------
  * One chain over several GPUs (cohorts too large or too slow for one): the joint logp is a sum over

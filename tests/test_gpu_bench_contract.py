@@ -56,8 +56,9 @@ def test_bench_line_has_the_contract_fields():
     assert nu["iterations"] >= 200 or nu["seconds"] >= 1.0
     assert d["nuts_evals_per_s"] < d["value"]
     # ... over the whole call and while all chains are still at work, on one shared and on four own discrete states
-    own = d["nuts_own_states"]
-    for x in (nu, own):
+    own, bal = d["nuts_own_states"], d["nuts_balanced"]
+    assert "pooled" in bal["note"]
+    for x in (nu, own, bal):
         assert x["value"] <= x["all_chains_at_work"] * 1.02 and 0 < x["first_chain_done_at"] <= 1.0 and len(x["leapfrogs_per_chain"]) == 4
     assert "own random discrete state" in own["note"] and "same discrete state" in nu["note"]
     # the compound step of abdpymc-infer at config 3: 4 chains x 200 iterations

@@ -744,3 +744,32 @@ def test_cli_on_a_config3_sized_cohort_directory_stays_within_the_host_budget(tm
     assert z["i"].shape == (4, 2, 200, 10000) and z["draw_index"].tolist() == [[0, 10]] * 4
     assert z["p"].shape == (4, 20) and np.isfinite(z["stat_lp"]).all()
     assert np.isfinite(z["mean_ab_s_mu"]).all() and 0.0 <= z["mean_i"].min() and z["mean_i"].max() <= 1.0
+
+
+def test_set_adaptation_installs_step_size_and_metric(test_td):
+    """abd_sampler_set_adaptation (pooled adaptation between runs): the chain takes the step size and the diagonal metric it is
+    given -- a draw run afterwards reports that step size -- and bad values are refused."""
+    from abdpymc_amd.model import model
+
+    m = model(test_td, splits=(14,), n_chains=2)
+    smp = m.ctx.sampler(np.arange(2), _start(m, 2, seed=2), tune=15, seed=1, gibbs=False)
+    smp.run(15)
+    im0, eps0 = smp.adaptation(0)
+    im1, eps1 = smp.adaptation(1)
+    im = np.sqrt(im0 * im1)
+    eps = float(np.sqrt(eps0 * eps1))
+    for k in range(2):
+        smp.set_adaptation(k, im, eps)
+        got_im, got_eps = smp.adaptation(k)
+        np.testing.assert_array_equal(got_im, im)
+        assert got_eps == eps
+    _, st = smp.run(5)
+    assert np.all(st["step_size"] == eps)
+    smp.set_adaptation(0, None, 0.5 * eps)  # step size alone
+    assert smp.adaptation(0)[1] == 0.5 * eps and np.array_equal(smp.adaptation(0)[0], im)
+    with pytest.raises(ValueError):
+        smp.set_adaptation(0, np.zeros(17), eps)
+    with pytest.raises(ValueError):
+        smp.set_adaptation(5, im, eps)
+    smp.close()
+    m.close()

@@ -49,7 +49,7 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
   // beside it (12 waves x 168 registers fill the CU's register file); the sweep itself 0.39 -> 0.41 ms, the compound
   // iteration of 4 chains at config 3 6.17 -> 5.90 ms.  Trajectories do not depend on the launch shape.
   if (m == 1) nw2 = std::max(4, std::min(nw2, tune_int("ABD_G2_WAVES_ONE", 8)));
-  if (c->dense && !c->gibbs_v1 && nw2 >= 4 && c->nt <= ABD_MAXT) {  // (the lane-per-proposal kernel is built for <= 256 gaps)
+  if (c->dense && !c->gibbs_v1 && nw2 >= 4) {  // (4 or 8 words per individual: <= 256 / <= 512 gaps)
     // lanes = proposals (abd_gibbs2.hpp): one workgroup per CU, the individuals of a chain handed out from one queue
     // per chain
     const size_t lds2 = abd_g2_lds(c->G, rbytes, nw2);
@@ -65,10 +65,16 @@ int enqueue_gibbs(abd_ctx* c, int m, const int32_t* chains, const double* theta,
       return hipSuccess;
     };
     const bool f32 = c->storage == ABD_STORE_F32;
-    if (stats_dev)  // ABD_GIBBS_STATS=1: the variant with the scheduler's development counters
-      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, true>) : launch2(abd_gibbs_dense_kernel<double, true>));
-    else
-      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, false>) : launch2(abd_gibbs_dense_kernel<double, false>));
+    if (c->nt > ABD_MAXT) {
+      if (stats_dev)  // ABD_GIBBS_STATS=1: the variant with the scheduler's development counters
+        HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, true, ABD_MAXT_MAX>) : launch2(abd_gibbs_dense_kernel<double, true, ABD_MAXT_MAX>));
+      else
+        HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, false, ABD_MAXT_MAX>) : launch2(abd_gibbs_dense_kernel<double, false, ABD_MAXT_MAX>));
+    } else if (stats_dev) {
+      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, true, ABD_MAXT>) : launch2(abd_gibbs_dense_kernel<double, true, ABD_MAXT>));
+    } else {
+      HIP_TRY(f32 ? launch2(abd_gibbs_dense_kernel<float, false, ABD_MAXT>) : launch2(abd_gibbs_dense_kernel<double, false, ABD_MAXT>));
+    }
   } else {
     const int blocks = std::max(1, std::min((c->N + ABD_WAVES_PER_BLOCK - 1) / ABD_WAVES_PER_BLOCK, c->n_cu * 8));
     const size_t lds = (size_t)3 * (c->G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * abd_gibbs_wave_lds(c->G);

@@ -9,11 +9,10 @@
 //                           a wave-wide sum, and a pass over the packed words on the scalar unit
 //   abd_gibbs_dense_kernel  LANES = PROPOSALS.  Almost every proposal is rejected (0.05 - 2 acceptances per individual
 //                           and sweep), so the next proposals in the individual's random order are evaluated
-//                           SPECULATIVELY against the current state, each by its own lane: the lane applies the
-//                           constraints to its flipped column (abd.py:640-667; the three-gap pass restarts at the
-//                           first changed gap), then walks gap by gap from the first gap whose constrained infection
-//                           changes, carrying the two responses by the recurrence (abd.py:288) and adding up the new
-//                           likelihood terms.  Every term is <= 0, so
+//                           SPECULATIVELY against the current state, each by its own lane: the lane works out how the
+//                           flip changes the constrained infections (abd.py:640-667), then walks gap by gap from the
+//                           first gap whose constrained infection changes, carrying the two responses by the
+//                           recurrence (abd.py:288) and adding up the new likelihood terms.  Every term is <= 0, so
 //                               delta  <=  (prior delta - sum of the CURRENT terms from that gap on) + (new terms so far)
 //                           and the lane stops as soon as that bound falls below log u -- typically 3-10 gaps after a
 //                           new infection -- or at the last gap, where the bound IS delta.  Lanes that finish pick up
@@ -24,8 +23,25 @@
 //                           ab_s_waner proposal changes every gap and is evaluated by the whole wave when the frontier
 //                           reaches it.  The trajectory is therefore exactly the sequential one.
 //
-// Per wave in LDS: the individual's OD pairs of both antigens, the two responses at the current state per gap, the
-// suffix sums of the current terms, log u per dim, the proposal list and one result byte per proposal.
+// The individual's state lives in LDS as what a proposal needs of it, not as packed rows in scalar registers (rounds 2 and 3:
+// five rows of 4 -- or 8 -- 64-bit words held wave-uniform filled the scalar file: 210 spilled registers, a scratch array for
+// the per-lane row index, and no room for cohorts beyond 256 gaps):
+//   * i0 (the infections before the three-gap pass: abd.py:643-647, or per time chunk abd.py:818 + 771), the kept
+//     infections I and the vaccinations as SORTED POSITION LISTS -- an individual has a handful of each;
+//   * per time chunk: does PCR+ decide it, and the first two raw infections in it.  A flip of raw bit d then changes i0 by
+//     at most one position leaving and one entering, worked out from those few numbers;
+//   * the three-gap pass restarted at the first changed position is a walk over the i0 list (abd.py:560-601: a set bit is
+//     kept iff no kept bit lies in the three gaps before it), compared entry by entry with the current I list: the first
+//     difference is the gap the lane's walk starts at, and the new kept infections from there on are the lane's own short
+//     list (ABD_G2_KCAP entries; a proposal that needs more -- e.g. on an all-ones i_raw -- is evaluated by the whole wave at
+//     the frontier, like the waning flip);
+//   * the walk meets infections and vaccinations by comparing its gap with the next list entry.
+// The packed rows themselves are kept in LDS too (the raw row for the flip's old value, all rows for the whole-wave
+// evaluations and the write-back) and only pass through scalar registers where a whole-wave evaluation runs.  Nothing here
+// depends on the number of words: the kernel is a template on it (4: <= 256 gaps, 8: <= 512) only for those evaluations.
+//
+// Per wave in LDS: the individual's OD pairs of both antigens, the suffix sums of the current terms, log u per dim, the
+// proposal list, one result byte per proposal, the rows, the position lists and the lanes' new-infection lists.
 #pragma once
 
 #include "abd_gibbs.hpp"
@@ -35,18 +51,45 @@
 #define ABD_G2_ACCEPT 2
 #define ABD_G2_COMPLEX 3
 #define ABD_G2_ITER_CAP (1 << 20)    // hard bound on scheduler iterations per individual (never reached: see the loop)
+#define ABD_G2_KCAP 8                // new kept infections (from the first changed gap on) a lane holds for its walk
+#define ABD_G2_NONE (1 << 20)        // "no position"
 
 #define ABD_G2_MAX_WAVES 12  // waves of a workgroup (= of a CU: one workgroup per CU, three waves per SIMD, <= 168 registers)
 __host__ __device__ inline size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 * 16; }
-// per-wave LDS bytes (9.6 KB at G = 200, fp64: LDS, not registers, decides how many waves a CU holds)
-__host__ __device__ inline size_t abd_g2_wave_lds(int G, int rbytes) {
-  size_t b = abd_g2_pad16((size_t)G * 2 * rbytes) * 2;  // {od, log_dilution} per gap, N then S
-  b += abd_g2_pad16((size_t)(G + 1) * 8);                // suf[g] = -(sum of the current terms of gaps >= g); suf[G] = 0
-  b += abd_g2_pad16((size_t)(G + 1) * 4);                // the acceptance draw's Philox word by dim
-  b += abd_g2_pad16((size_t)(G + 1) * 2);                // proposal list: dim by position in the sweep
-  b += abd_g2_pad16((size_t)(G + 1));                    // result by position
-  return b;
+__host__ __device__ inline int abd_g2_words(int G) { return (G + 63) / 64 > ABD_MAXT ? ABD_MAXT_MAX : ABD_MAXT; }
+// per-wave LDS bytes (12.4 KB at G = 200, fp64: LDS, not registers, decides how many waves a CU holds)
+struct G2Layout {
+  size_t dataS, suf, accw, plist, result, rows, epos, i0pos, ipos, vpos, inl, total;
+};
+__host__ __device__ inline G2Layout abd_g2_layout(int G, int rbytes) {
+  G2Layout L;
+  size_t b = abd_g2_pad16((size_t)G * 2 * rbytes);  // {od, log_dilution} per gap, N ...
+  L.dataS = b;
+  b += abd_g2_pad16((size_t)G * 2 * rbytes);         // ... then S
+  L.suf = b;
+  b += abd_g2_pad16((size_t)(G + 1) * 8);            // suf[g] = -(sum of the current terms of gaps >= g); suf[G] = 0
+  L.accw = b;
+  b += abd_g2_pad16((size_t)(G + 1) * 4);            // the acceptance draw's Philox word by dim
+  L.plist = b;
+  b += abd_g2_pad16((size_t)(G + 1) * 2);            // proposal list: dim by position in the sweep
+  L.result = b;
+  b += abd_g2_pad16((size_t)(G + 1));                // result by position
+  L.rows = b;
+  b += abd_g2_pad16((size_t)4 * abd_g2_words(G) * 8);  // packed rows: vaccinations, PCR+, i_raw, kept infections I
+  L.epos = b;
+  b += abd_g2_pad16((size_t)2 * (G + 1) * 2);        // exposures in the order their responses are summed: per 64-gap word the kept infections, then the vaccinations (bit 15: a vaccination)
+  L.i0pos = b;
+  b += abd_g2_pad16((size_t)(G + 1) * 2);            // positions of i0, ascending
+  L.ipos = b;
+  b += abd_g2_pad16((size_t)(G / 4 + 2) * 2);        // positions of the kept infections I, ascending (at most one in four gaps)
+  L.vpos = b;
+  b += abd_g2_pad16((size_t)(G + 1) * 2);            // positions of the vaccinations, ascending
+  L.inl = b;
+  b += (size_t)ABD_G2_KCAP * 64 * 2;                 // [ABD_G2_KCAP][64] a lane's new kept infections from its first changed gap on
+  L.total = b;
+  return L;
 }
+__host__ __device__ inline size_t abd_g2_wave_lds(int G, int rbytes) { return abd_g2_layout(G, rbytes).total; }
 // LDS of the tables every wave of the workgroup shares: [2][G+1] power tables + [G+1] ones + 2^(j/1024)
 __host__ __device__ inline size_t abd_g2_shared_lds(int G) {
   return (size_t)3 * (G + 1) * sizeof(double2_t) + (size_t)ABD_EXP2_TAB * sizeof(double);
@@ -63,21 +106,22 @@ __host__ __device__ inline size_t abd_g2_lds(int G, int rbytes, int n_waves) {
 
 // i0 of constrain_infections before the three-gap pass (abd.py:643-647 one chunk; abd.py:818 + 771 per chunk otherwise).
 // Works on wave-uniform and on per-lane words alike.
-__device__ __forceinline__ void constrain_i0(const uint64_t raw[ABD_MAXT], const uint64_t pcr[ABD_MAXT], const EvalArgs& a,
-                                             uint64_t i0[ABD_MAXT]) {
+template <int MT>
+__device__ __forceinline__ void constrain_i0(const uint64_t (&raw)[MT], const uint64_t (&pcr)[MT], const EvalArgs& a,
+                                             uint64_t (&i0)[MT]) {
   if (a.n_chunks <= 1) {
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) i0[t] = raw[t] | pcr[t];
+    for (int t = 0; t < MT; ++t) i0[t] = raw[t] | pcr[t];
   } else {
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) i0[t] = 0;
+    for (int t = 0; t < MT; ++t) i0[t] = 0;
     for (int c = 0; c < a.n_chunks; ++c) {
       bool has_pcr = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) has_pcr |= (pcr[t] & a.chunk_mask[c][t]) != 0;
+      for (int t = 0; t < MT; ++t) has_pcr |= (pcr[t] & a.chunk_mask[c][t]) != 0;
       bool found = false;
 #pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t) {
+      for (int t = 0; t < MT; ++t) {
         const uint64_t cm = a.chunk_mask[c][t];
         const uint64_t r = raw[t] & cm;
         const uint64_t first = found ? 0ull : (r & (0ull - r));
@@ -90,14 +134,15 @@ __device__ __forceinline__ void constrain_i0(const uint64_t raw[ABD_MAXT], const
 
 // mask_three_gaps (abd.py:560-601) restarted at gap p0: the kept infections before p0 (`before` = I & bits below p0) are
 // what they were -- the pass is causal -- and the greedy pass goes on from the last of them over the bits of i0 at >= p0.
-__device__ __forceinline__ void three_gaps_from(const uint64_t i0[ABD_MAXT], const uint64_t before[ABD_MAXT], int p0,
-                                                uint64_t out[ABD_MAXT]) {
+template <int MT>
+__device__ __forceinline__ void three_gaps_from(const uint64_t (&i0)[MT], const uint64_t (&before)[MT], int p0,
+                                                uint64_t (&out)[MT]) {
   int block_until = 0;
 #pragma unroll
-  for (int t = ABD_MAXT - 1; t >= 0; --t)
+  for (int t = MT - 1; t >= 0; --t)
     if (before[t] != 0 && block_until == 0) block_until = t * 64 + 63 - __builtin_clzll(before[t]) + 4;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     const int rel = p0 - t * 64;  // bits >= rel of word t are at or after p0
     const uint64_t from = rel <= 0 ? ~0ull : (rel >= 64 ? 0ull : ~((1ull << rel) - 1ull));
     uint64_t m = i0[t] & from;
@@ -115,31 +160,24 @@ __device__ __forceinline__ void three_gaps_from(const uint64_t i0[ABD_MAXT], con
   }
 }
 
-__device__ __forceinline__ int first_bit(const uint64_t w[ABD_MAXT]) {  // position of the lowest set bit, or 1 << 20
+template <int MT>
+__device__ __forceinline__ int first_bit(const uint64_t (&w)[MT]) {  // position of the lowest set bit, or 1 << 20
   int p = 1 << 20;
 #pragma unroll
-  for (int t = ABD_MAXT - 1; t >= 0; --t)
+  for (int t = MT - 1; t >= 0; --t)
     if (w[t] != 0) p = t * 64 + __builtin_ctzll(w[t]);
   return p;
 }
 
-// word (g >> 6) of a per-lane or uniform row, g per lane; compile-time indices only
-__device__ __forceinline__ uint64_t word_at(const uint64_t w[ABD_MAXT], int g) {
-  const int t = g >> 6;
-  uint64_t v = w[0];
-#pragma unroll
-  for (int q = 1; q < ABD_MAXT; ++q) v = t == q ? w[q] : v;
-  return v;
-}
-
 // a wave-uniform row shifted down by g gaps (bit 0 of the result = gap g)
-__device__ __forceinline__ void shift_row_down(const uint64_t w[ABD_MAXT], int g, uint64_t out[ABD_MAXT]) {
+template <int MT>
+__device__ __forceinline__ void shift_row_down(const uint64_t (&w)[MT], int g, uint64_t (&out)[MT]) {
   const int q = g >> 6, sh = g & 63;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
+  for (int t = 0; t < MT; ++t) {
     uint64_t lo = 0, hi = 0;
 #pragma unroll
-    for (int k = 0; k < ABD_MAXT; ++k) {
+    for (int k = 0; k < MT; ++k) {
       lo = t + q == k ? w[k] : lo;
       hi = t + q + 1 == k ? w[k] : hi;
     }
@@ -185,19 +223,18 @@ struct G2Par {  // wave-uniform constants of the chain
 // (carry into the round x rho^(lane+1) + this round's exposures at or before the lane, power table) and the term there.
 // The rounds start at gap g_off (0: the whole individual; otherwise I and V are the rows shifted down by g_off and
 // cvn / cvs / ci / civ the state at gap g_off - 1: the rest of one lane's walk, taken over by the whole wave).
-template <typename R>
-__device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint64_t I[ABD_MAXT],
-                                               const uint64_t V[ABD_MAXT], const double2_t* tab_n, const double2_t* tab_s,
+template <typename R, int MT>
+__device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint64_t (&I)[MT],
+                                               const uint64_t (&V)[MT], const double2_t* tab_n, const double2_t* tab_s,
                                                double pwn, double pws, const YX<R>* dataN, const YX<R>* dataS,
-                                               const double* tab_e2, double (&un_o)[ABD_MAXT], double (&us_o)[ABD_MAXT],
-                                               double (&term_o)[ABD_MAXT], int g_off = 0, double cvn = 0.0, double cvs = 0.0,
-                                               bool ci = false, bool civ = false) {
+                                               const double* tab_e2, double (&term_o)[MT], int g_off = 0, double cvn = 0.0,
+                                               double cvs = 0.0, bool ci = false, bool civ = false) {
   // cvn / cvs: responses at the end of the previous round (wave-uniform)
   const uint64_t le = (2ull << lane) - 1ull;  // bits at or before this lane (lane 63: all ones)
   const int n_rounds = (a.G - g_off + 63) >> 6;
 #pragma unroll
-  for (int t = 0; t < ABD_MAXT; ++t) {
-    un_o[t] = us_o[t] = term_o[t] = 0.0;
+  for (int t = 0; t < MT; ++t) {
+    term_o[t] = 0.0;
     if (t < n_rounds) {
       double un = pwn * cvn, us = pws * cvs;
       uint64_t m = I[t];
@@ -224,8 +261,6 @@ __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p
       const double as = p.init_s + (cum_iv ? p.perm_s : 0.0) + us;
       const double term = g2_term(an, (double)on.x, (double)on.y, p.c_n, p.d_n, p.nh_n, as, (double)os.x, (double)os.y, p.c_s,
                                   p.d_s, p.nh_s, tab_e2);
-      un_o[t] = un;
-      us_o[t] = us;
       term_o[t] = valid ? term : 0.0;
       cvn = readlane_f64(un, 63);
       cvs = readlane_f64(us, 63);
@@ -242,15 +277,15 @@ __device__ __forceinline__ uint32_t bitonic_lane_step(uint32_t key, int lane, bo
   const bool lower = (lane & J) == 0;
   return (lower == ascending) ? min(key, other) : max(key, other);
 }
-template <int K, int J>
-__device__ __forceinline__ void bitonic_stage(uint32_t (&k)[4], int lane) {
-  // element e = r * 64 + lane; direction of its sub-sequence: ascending iff (e & K) == 0
+// element e = r * 64 + lane of NR x 64 keys; direction of its sub-sequence: ascending iff (e & K) == 0 (the last merge: all)
+template <int NR, int K, int J>
+__device__ __forceinline__ void bitonic_stage(uint32_t (&k)[NR], int lane) {
   if (J >= 64) {
     constexpr int dr = J / 64;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NR; ++r) {
       if ((r & dr) == 0) {
-        const bool asc = K >= 256 ? true : ((r * 64) & K) == 0;
+        const bool asc = K >= NR * 64 ? true : ((r * 64) & K) == 0;
         const uint32_t lo = min(k[r], k[r | dr]), hi = max(k[r], k[r | dr]);
         k[r] = asc ? lo : hi;
         k[r | dr] = asc ? hi : lo;
@@ -258,38 +293,62 @@ __device__ __forceinline__ void bitonic_stage(uint32_t (&k)[4], int lane) {
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool asc = K >= 256 ? true : (K >= 64 ? ((r * 64) & K) == 0 : (lane & K) == 0);
+    for (int r = 0; r < NR; ++r) {
+      const bool asc = K >= NR * 64 ? true : (K >= 64 ? ((r * 64) & K) == 0 : (lane & K) == 0);
       k[r] = bitonic_lane_step<(J < 64 ? J : 1)>(k[r], lane, asc);
     }
   }
 }
-template <int K, int J>
+template <int NR, int K, int J>
 struct BitonicJ {
-  static __device__ __forceinline__ void run(uint32_t (&k)[4], int lane) {
-    bitonic_stage<K, J>(k, lane);
-    BitonicJ<K, J / 2>::run(k, lane);
+  static __device__ __forceinline__ void run(uint32_t (&k)[NR], int lane) {
+    bitonic_stage<NR, K, J>(k, lane);
+    BitonicJ<NR, K, J / 2>::run(k, lane);
   }
 };
-template <int K>
-struct BitonicJ<K, 0> {
-  static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
+template <int NR, int K>
+struct BitonicJ<NR, K, 0> {
+  static __device__ __forceinline__ void run(uint32_t (&)[NR], int) {}
 };
-// ascending sort of 256 keys, 4 per lane (element e = register e / 64 of lane e % 64): 36 compare-exchange stages
-__device__ __forceinline__ void bitonic_sort_256(uint32_t (&k)[4], int lane) {
-  BitonicJ<2, 1>::run(k, lane);
-  BitonicJ<4, 2>::run(k, lane);
-  BitonicJ<8, 4>::run(k, lane);
-  BitonicJ<16, 8>::run(k, lane);
-  BitonicJ<32, 16>::run(k, lane);
-  BitonicJ<64, 32>::run(k, lane);
-  BitonicJ<128, 64>::run(k, lane);
-  BitonicJ<256, 128>::run(k, lane);
+template <int NR, int K>
+struct BitonicK {
+  static __device__ __forceinline__ void run(uint32_t (&k)[NR], int lane) {
+    BitonicK<NR, K / 2>::run(k, lane);
+    BitonicJ<NR, K, K / 2>::run(k, lane);
+  }
+};
+template <int NR>
+struct BitonicK<NR, 1> {
+  static __device__ __forceinline__ void run(uint32_t (&)[NR], int) {}
+};
+// ascending sort of NR x 64 keys, NR per lane (element e = register e / 64 of lane e % 64): 36 compare-exchange stages for
+// 256 keys, 45 for 512
+template <int NR>
+__device__ __forceinline__ void bitonic_sort(uint32_t (&k)[NR], int lane) {
+  BitonicK<NR, NR * 64>::run(k, lane);
 }
 
-// STATS: the development counters of ABD_GIBBS_STATS=1 (seven wave-uniform 64-bit counters: 14 scalar registers the product
-// kernel does not have to spare)
-template <typename R, bool STATS>
+// a packed row of the wave's individual from LDS into scalar registers
+template <int MT>
+__device__ __forceinline__ void g2_load_row(const uint64_t* row /* LDS */, uint64_t (&w)[MT]) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const uint64_t v = row[t];
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    w[t] = ((uint64_t)hi << 32) | lo;
+  }
+}
+// positions of the set bits of word t of a wave-uniform row, ascending, appended to list[n ..) (LDS; lanes = bits); returns the new count
+__device__ __forceinline__ int g2_append_positions(uint64_t m, int t, int lane, uint16_t* list, int n, uint16_t flag) {
+  if (m != 0) {  // (wave-uniform)
+    if ((m >> lane) & 1ull) list[n + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)(t * 64 + lane) | flag;
+    n += __builtin_popcountll(m);
+  }
+  return n;
+}
+
+// STATS: the development counters of ABD_GIBBS_STATS=1 (seven wave-uniform 64-bit counters)
+template <typename R, bool STATS, int MT>
 __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
@@ -301,13 +360,23 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_threads = (int)blockDim.x;  // 64 x the waves that fit the CU's LDS (abd_g2_waves)
-  unsigned char* wb = reinterpret_cast<unsigned char*>(tab_e2 + ABD_EXP2_TAB) + (size_t)wave * abd_g2_wave_lds(G, (int)sizeof(R));
+  const G2Layout L = abd_g2_layout(G, (int)sizeof(R));
+  unsigned char* wb = reinterpret_cast<unsigned char*>(tab_e2 + ABD_EXP2_TAB) + (size_t)wave * L.total;
   YX<R>* dataN = reinterpret_cast<YX<R>*>(wb);
-  YX<R>* dataS = reinterpret_cast<YX<R>*>(wb + abd_g2_pad16((size_t)G * sizeof(YX<R>)));
-  double* suf = reinterpret_cast<double*>(wb + 2 * abd_g2_pad16((size_t)G * sizeof(YX<R>)));
-  uint32_t* accw = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(suf) + abd_g2_pad16((size_t)(G + 1) * 8));
-  uint16_t* plist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(accw) + abd_g2_pad16((size_t)(G + 1) * 4));
-  unsigned char* result = reinterpret_cast<unsigned char*>(plist) + abd_g2_pad16((size_t)(G + 1) * 2);
+  YX<R>* dataS = reinterpret_cast<YX<R>*>(wb + L.dataS);
+  double* suf = reinterpret_cast<double*>(wb + L.suf);
+  uint32_t* accw = reinterpret_cast<uint32_t*>(wb + L.accw);
+  uint16_t* plist = reinterpret_cast<uint16_t*>(wb + L.plist);
+  unsigned char* result = wb + L.result;
+  uint64_t* row_v = reinterpret_cast<uint64_t*>(wb + L.rows);  // packed rows of the individual: vaccinations,
+  uint64_t* row_p = row_v + MT;                                 // PCR+,
+  uint64_t* row_r = row_p + MT;                                 // i_raw,
+  uint64_t* row_i = row_r + MT;                                 // the kept infections I = constrain(i_raw, pcrpos)
+  uint16_t* epos = reinterpret_cast<uint16_t*>(wb + L.epos);
+  uint16_t* i0pos = reinterpret_cast<uint16_t*>(wb + L.i0pos);
+  uint16_t* ipos = reinterpret_cast<uint16_t*>(wb + L.ipos);
+  uint16_t* vpos = reinterpret_cast<uint16_t*>(wb + L.vpos);
+  uint16_t* inl = reinterpret_cast<uint16_t*>(wb + L.inl) + lane;  // this lane's list: entry k at inl[k * 64]
 
   const int c = blockIdx.y;  // one chain per block row
   const ChainPar& cp = a.ch[c];
@@ -317,8 +386,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   for (int e = tid; e < ABD_EXP2_TAB; e += n_threads) tab_e2[e] = a.exp2_tab[e];
   __syncthreads();
 
-  // the chain's constants live in VECTOR registers: the scalar file is needed for the packed rows of the individual
-  // (five rows of four words), and a spilled scalar costs a v_readlane in the walk
+  // the chain's constants live in VECTOR registers (a spilled scalar costs a v_readlane in the walk)
   G2Par p;
   p.perm_n = to_vgpr(cp.perm_n);
   p.temp_n = to_vgpr(cp.temp_n);
@@ -341,8 +409,21 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   uint64_t* rw = const_cast<uint64_t*>(cp.rw);
   int8_t* waner = const_cast<int8_t*>(cp.waner);
   uint64_t* iw = const_cast<uint64_t*>(cp.iw);
+  // where the time chunks begin (abd.py:865-882; an empty chunk begins nowhere)
+  int chunk_lo1 = ABD_G2_NONE, chunk_lo2 = ABD_G2_NONE;
+  if (a.n_chunks > 1) {
+    uint64_t cm[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) cm[t] = a.chunk_mask[1][t];
+    chunk_lo1 = first_bit<MT>(cm);
+    if (a.n_chunks > 2) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) cm[t] = a.chunk_mask[2][t];
+      chunk_lo2 = first_bit<MT>(cm);
+    }
+  }
   int d_n1 = 0, d_m1 = 0;  // changes of sum(i_raw), sum(ab_s_waner) over this wave's individuals
-  unsigned long long n_acc = 0, n_prop_total = 0;
+  unsigned int n_acc = 0, n_prop_total = 0;
   unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
   for (;;) {
@@ -354,85 +435,149 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     j = __builtin_amdgcn_readfirstlane(j);
     if (j >= N) break;
 
-    // ---- this individual's discrete state and data ----
-    uint64_t V[ABD_MAXT], P[ABD_MAXT], Rw[ABD_MAXT], I[ABD_MAXT], I0[ABD_MAXT];
+    // ---- this individual's discrete state and data: into LDS ----
+    int firstV = ABD_G2_NONE, n_v = 0, pc0 = 0;
+    {
+      uint64_t V[MT], P[MT], Rw[MT];
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) {
-      V[t] = P[t] = Rw[t] = 0;
-      if (t < nt) {
-        V[t] = uniform_word(a.vw, (int64_t)t * N + j);
-        if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
-        Rw[t] = uniform_word(rw, (int64_t)t * N + j);
-        const int g = t * 64 + lane;
-        if (g < G) {  // the individual's gap axis from the individual-major copy: contiguous, 1 KB per wave load
-          dataN[g] = reinterpret_cast<const YX<R>*>(a.yxi_n)[(int64_t)j * G + g];
-          dataS[g] = reinterpret_cast<const YX<R>*>(a.yxi_s)[(int64_t)j * G + g];
+      for (int t = 0; t < MT; ++t) {
+        V[t] = P[t] = Rw[t] = 0;
+        if (t < nt) {
+          V[t] = uniform_word(a.vw, (int64_t)t * N + j);
+          if (a.pw) P[t] = uniform_word(a.pw, (int64_t)t * N + j);
+          Rw[t] = uniform_word(rw, (int64_t)t * N + j);
         }
+      }
+      for (int g = lane; g < G; g += 64) {  // the individual's gap axis from the individual-major copy: contiguous, 1 KB per wave load
+        dataN[g] = reinterpret_cast<const YX<R>*>(a.yxi_n)[(int64_t)j * G + g];
+        dataS[g] = reinterpret_cast<const YX<R>*>(a.yxi_s)[(int64_t)j * G + g];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          row_v[t] = V[t];
+          row_p[t] = P[t];
+          row_r[t] = Rw[t];
+        }
+      }
+      firstV = first_bit<MT>(V);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        n_v = g2_append_positions(V[t], t, lane, vpos, n_v, 0);
+        pc0 += __builtin_popcountll(Rw[t]);
       }
     }
     bool wj = __builtin_amdgcn_readfirstlane((int)waner[j]) != 0;
-    const int firstV = first_bit(V);
-    int pc0 = wj ? (1 << 16) : 0;  // sum(i_raw) and ab_s_waner of this individual before the sweep
-#pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) pc0 += __builtin_popcountll(Rw[t]);
+    pc0 += wj ? (1 << 16) : 0;  // sum(i_raw) and ab_s_waner of this individual before the sweep
 
     // ---- random order of this individual's proposals ----
     // Philox words as abd_gibbs_kernel: word 0 orders the dims (low 9 bits = the dim), word 1 < 0.8 2^32 proposes the
     // dim, word 2 is the acceptance uniform.  Dims that are not proposed never enter the list.
-    uint32_t key[4];
-    int n_prop = 0;
+    int n_prop = 0, w_rank = 0;
+    bool w_proposed;
+    {
+      uint32_t key[MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int d = r * 64 + lane;
-      key[r] = 0xFFFFFFFFu;
-      if (d < G) {
-        const Philox4 rr = philox4x32_10((uint32_t)d, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
-        if (rr.w[1] < ABD_TRANSIT_P_U32) {
-          key[r] = (rr.w[0] & ~0x1FFu) | (uint32_t)d;
-          accw[d] = rr.w[2];
+      for (int r = 0; r < MT; ++r) {
+        const int d = r * 64 + lane;
+        key[r] = 0xFFFFFFFFu;
+        if (d < G) {
+          const Philox4 rr = philox4x32_10((uint32_t)d, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
+          if (rr.w[1] < ABD_TRANSIT_P_U32) {
+            key[r] = (rr.w[0] & ~0x1FFu) | (uint32_t)d;
+            accw[d] = rr.w[2];
+          }
         }
+        n_prop += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[r] != 0xFFFFFFFFu));
       }
-      n_prop += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[r] != 0xFFFFFFFFu));
-    }
-    bitonic_sort_256(key, lane);
-    // the ab_s_waner dim (dim G) takes its place among them
-    const Philox4 rwz = philox4x32_10((uint32_t)G, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
-    const bool w_proposed = rwz.w[1] < ABD_TRANSIT_P_U32;
-    const uint32_t w_key = (rwz.w[0] & ~0x1FFu) | (uint32_t)G;
-    int w_rank = 0;  // proposed i_raw dims ordered before it
+      bitonic_sort<MT>(key, lane);
+      // the ab_s_waner dim (dim G) takes its place among them
+      const Philox4 rwz = philox4x32_10((uint32_t)G, (uint32_t)j + ga.ind_offset, cs, 0u, k0, k1);
+      w_proposed = rwz.w[1] < ABD_TRANSIT_P_U32;
+      const uint32_t w_key = (rwz.w[0] & ~0x1FFu) | (uint32_t)G;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w_rank += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[r] < w_key));
-    if (!w_proposed) w_rank = 1 << 20;
+      for (int r = 0; r < MT; ++r) w_rank += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[r] < w_key));  // proposed i_raw dims ordered before it
+      if (!w_proposed) w_rank = 1 << 20;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = r * 64 + lane;
-      if (key[r] != 0xFFFFFFFFu) plist[e + (e >= w_rank ? 1 : 0)] = (uint16_t)(key[r] & 0x1FFu);
-    }
-    if (w_proposed) {
-      if (lane == 0) {
-        plist[w_rank] = (uint16_t)G;
-        accw[G] = rwz.w[2];
+      for (int r = 0; r < MT; ++r) {
+        const int e = r * 64 + lane;
+        if (key[r] != 0xFFFFFFFFu) plist[e + (e >= w_rank ? 1 : 0)] = (uint16_t)(key[r] & 0x1FFu);
       }
-      n_prop += 1;
+      if (w_proposed) {
+        if (lane == 0) {
+          plist[w_rank] = (uint16_t)G;
+          accw[G] = rwz.w[2];
+        }
+        n_prop += 1;
+      }
     }
     for (int e = lane; e <= G; e += 64) result[e] = ABD_G2_PENDING;
 
-    // ---- the current state: constrained infections, responses, terms, suffix sums ----
+    // ---- the current state: constrained infections, position lists, chunk facts, terms, suffix sums ----
     double total_cur = 0.0;
-    int firstI = 1 << 20;
+    int firstI = ABD_G2_NONE, n_i = 0, n_i0 = 0, n_e = 0;
+    // per time chunk (several chunks only): bit c of chunk_pcr = PCR+ decides chunk c; the first two raw infections in it
+    int chunk_pcr = 0, f1_0 = ABD_G2_NONE, f1_1 = ABD_G2_NONE, f1_2 = ABD_G2_NONE, f2_0 = ABD_G2_NONE, f2_1 = ABD_G2_NONE, f2_2 = ABD_G2_NONE;
     auto refresh = [&]() {
-      constrain_i0(Rw, P, a, I0);
-      const uint64_t none[ABD_MAXT] = {0, 0, 0, 0};
-      three_gaps_from(I0, none, 0, I);
-      firstI = first_bit(I);
-      double un[ABD_MAXT], us[ABD_MAXT], term[ABD_MAXT];
-      g2_eval_rounds<R>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, un,
-                        us, term);
+      uint64_t V[MT], I[MT];
+      {
+        uint64_t Rw[MT], P[MT], I0[MT];
+        g2_load_row<MT>(row_r, Rw);
+        g2_load_row<MT>(row_p, P);
+        g2_load_row<MT>(row_v, V);
+        constrain_i0<MT>(Rw, P, a, I0);
+        uint64_t none[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) none[t] = 0;
+        three_gaps_from<MT>(I0, none, 0, I);
+        n_i = n_i0 = n_e = 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          n_i0 = g2_append_positions(I0[t], t, lane, i0pos, n_i0, 0);
+          n_i = g2_append_positions(I[t], t, lane, ipos, n_i, 0);
+          n_e = g2_append_positions(I[t], t, lane, epos, n_e, 0);
+          n_e = g2_append_positions(V[t], t, lane, epos, n_e, 0x8000u);
+        }
+        if (a.n_chunks > 1) {
+          chunk_pcr = 0;
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            int f1 = ABD_G2_NONE, f2 = ABD_G2_NONE;
+            if (cc < a.n_chunks) {
+              bool has = false;
+              uint64_t r[MT];
+#pragma unroll
+              for (int t = 0; t < MT; ++t) {
+                has |= (P[t] & a.chunk_mask[cc][t]) != 0;
+                r[t] = Rw[t] & a.chunk_mask[cc][t];
+              }
+              if (has) chunk_pcr |= 1 << cc;
+              f1 = first_bit<MT>(r);
+              if (f1 < ABD_G2_NONE) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                  if (t == (f1 >> 6)) r[t] &= r[t] - 1;  // (the lowest set bit of the row lies in this word)
+                f2 = first_bit<MT>(r);
+              }
+            }
+            if (cc == 0) f1_0 = f1, f2_0 = f2;
+            if (cc == 1) f1_1 = f1, f2_1 = f2;
+            if (cc == 2) f1_2 = f1, f2_2 = f2;
+          }
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) row_i[t] = I[t];
+      }
+      firstI = first_bit<MT>(I);
+      double term[MT];
+      g2_eval_rounds<R, MT>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, term);
       double carry = 0.0;
       int ln = lane;  // (opaque: left to itself the compiler hoists the scan's six "lane + off < 64" masks out of the
       asm volatile("" : "+v"(ln));  // individual loop and keeps them in 12 scalar registers for the whole kernel)
 #pragma unroll
-      for (int t = ABD_MAXT - 1; t >= 0; --t) {
+      for (int t = MT - 1; t >= 0; --t) {
         if (t < nt) {
           const int g = t * 64 + lane;
           double x = -term[t];  // >= 0; lanes past the last gap hold 0
@@ -450,7 +595,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       total_cur = -carry;
       __builtin_amdgcn_wave_barrier();
     };
-    __builtin_amdgcn_wave_barrier();  // the data rows are in LDS
+    __builtin_amdgcn_wave_barrier();  // the rows and the data are in LDS
     refresh();
 
     // ---- the sweep ----
@@ -460,7 +605,8 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     int pidx = 0, g = 0, g_first = 0;
     double tn = 0.0, ts = 0.0, S = 0.0, B0 = 0.0, thr = 0.0, lu = 0.0;
     uint32_t cfn_hi = 0, cfs_hi = 0;
-    uint64_t inw = 0, vw = 0, In[ABD_MAXT] = {0, 0, 0, 0};
+    int ki = 0, n_new = 0, next_i = ABD_G2_NONE;  // the lane's own list of new kept infections: next entry, count, its position
+    int kv = 0, next_v = ABD_G2_NONE;             // the next vaccination at or after the walk's gap
     const uint32_t z_ei = zero_vgpr(), z_ev = zero_vgpr(), z_cn = zero_vgpr(), z_cs = zero_vgpr();
 
     bool dirty = false;  // a result has been written since the last commit scan
@@ -485,69 +631,109 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
           if (d == G) {
             result[pidx] = ABD_G2_COMPLEX;  // ab_s_waner: evaluated by the whole wave at the frontier
           } else {
-            // the flipped column's constraints: i0, then the three-gap pass from the first gap where i0 changes
-            uint64_t Rn[ABD_MAXT], I0n[ABD_MAXT], X[ABD_MAXT], before[ABD_MAXT];
-            const int dw = d >> 6;
-            const uint64_t bit = 1ull << (d & 63);
-            bool was_one = false;
-#pragma unroll
-            for (int t = 0; t < ABD_MAXT; ++t) {
-              Rn[t] = Rw[t];
-              if (t == dw) {
-                was_one = (Rw[t] & bit) != 0;
-                Rn[t] ^= bit;
-              }
-            }
+            // how the flip of raw bit d changes i0 (abd.py:643-647 / 818 + 771): one position leaves (a_rm), one enters (b_add)
+            const bool was_one = ((row_r[d >> 6] >> (d & 63)) & 1ull) != 0;
             const double delta0 = was_one ? -theta0 : theta0;  // Bernoulli(i_raw | p) on the RAW matrix (abd.py:427)
-            constrain_i0(Rn, P, a, I0n);
-#pragma unroll
-            for (int t = 0; t < ABD_MAXT; ++t) X[t] = I0n[t] ^ I0[t];
-            int gf = 1 << 20;
-            const int p0 = first_bit(X);
-            if (p0 < (1 << 20)) {
-#pragma unroll
-              for (int t = 0; t < ABD_MAXT; ++t) {
-                const int rel = p0 - t * 64;
-                before[t] = I[t] & (rel <= 0 ? 0ull : (rel >= 64 ? ~0ull : ((1ull << rel) - 1ull)));
+            int a_rm = ABD_G2_NONE, b_add = ABD_G2_NONE;
+            if (a.n_chunks <= 1) {
+              const bool pcr_bit = a.pw != nullptr && ((row_p[d >> 6] >> (d & 63)) & 1ull) != 0;
+              if (!pcr_bit) {  // where(i_raw + pcrpos > 0, 1, 0): a PCR+ gap is an infection either way
+                if (was_one) a_rm = d;
+                else b_add = d;
               }
-              three_gaps_from(I0n, before, p0, In);
-#pragma unroll
-              for (int t = 0; t < ABD_MAXT; ++t) X[t] = In[t] ^ I[t];
-              gf = first_bit(X);
+            } else {
+              const int cc = (d >= chunk_lo1 ? 1 : 0) + (d >= chunk_lo2 ? 1 : 0);
+              const int f1 = cc == 0 ? f1_0 : (cc == 1 ? f1_1 : f1_2), f2 = cc == 0 ? f2_0 : (cc == 1 ? f2_1 : f2_2);
+              if (!((chunk_pcr >> cc) & 1)) {  // (a chunk with a PCR+ is that PCR+ column whatever i_raw holds: abd.py:771)
+                if (was_one) {
+                  if (d == f1) {  // the chunk's first raw infection goes: the second one (if any) takes its place (abd.py:818)
+                    a_rm = d;
+                    b_add = f2;
+                  }
+                } else if (d < f1) {  // a raw infection in front of the chunk's first one replaces it
+                  b_add = d;
+                  a_rm = f1;
+                }
+              }
             }
-            if (gf >= (1 << 20)) {
+            const int p0 = min(a_rm, b_add);
+            int gf = ABD_G2_NONE;
+            bool overflow = false;
+            if (p0 < ABD_G2_NONE) {
+              // the three-gap pass (abd.py:560-601) restarted at p0: the kept infections before p0 stay (the pass is causal)
+              int block_until = 0, kc = 0;  // kc: the current kept infections ipos[kc ..) lie at or after p0
+              for (int k = 0; k < n_i; ++k) {
+                const int pos = ipos[k];
+                if (pos < p0) {
+                  block_until = pos + 4;
+                  kc = k + 1;
+                }
+              }
+              // ... goes on over the new i0 from p0 on, compared entry by entry with the current kept infections: the first
+              // difference is the first gap whose constrained infection changes
+              n_new = 0;
+              ki = -1;  // index of the first new entry that differs from the current list
+              auto consider = [&](int gc) {
+                if (gc >= block_until) {
+                  if (n_new < ABD_G2_KCAP) inl[n_new * 64] = (uint16_t)gc;
+                  if (ki < 0) {
+                    const int cur = kc < n_i ? (int)ipos[kc] : ABD_G2_NONE;
+                    if (cur != gc) {
+                      gf = min(cur, gc);
+                      ki = n_new;
+                    } else {
+                      ++kc;
+                    }
+                  }
+                  ++n_new;
+                  block_until = gc + 4;
+                }
+              };
+              bool b_pending = b_add < ABD_G2_NONE;
+              for (int k = 0; k < n_i0; ++k) {
+                const int pos = i0pos[k];
+                if (pos >= p0 && pos != a_rm) {
+                  if (b_pending && b_add < pos) {
+                    consider(b_add);
+                    b_pending = false;
+                  }
+                  consider(pos);
+                }
+              }
+              if (b_pending) consider(b_add);
+              if (ki < 0 && kc < n_i) {  // the new list ended first: the next current infection is the first one that goes
+                gf = ipos[kc];
+                ki = n_new;
+              }
+              overflow = n_new > ABD_G2_KCAP;
+            }
+            if (gf >= ABD_G2_NONE) {
               // the constrained infections do not change: the prior term decides
               result[pidx] = (delta0 > 0.0 || delta0 > lu) ? ABD_G2_ACCEPT : ABD_G2_REJECT;
+            } else if (overflow) {
+              result[pidx] = ABD_G2_COMPLEX;  // more new infections than a lane holds: the whole wave evaluates it at the frontier
             } else {
               B0 = delta0 + suf[gf];  // everything the current state holds from gf on is given up
               thr = lu - 1e-9 * (fabs(B0) + 1.0);
               // the two responses at gap gf - 1 of the CURRENT state (the states agree below gf): the dense design
-              // (abd.py:258-274) summed over the current exposures, wave-uniform loops, per-lane table index
+              // (abd.py:258-274) summed over the current exposures before gf, in the order of the packed rows' words
               {
                 const double2_t* tsb = wj ? tabs + tstride : tab_ones;
                 tn = ts = 0.0;
-#pragma unroll
-                for (int t = 0; t < ABD_MAXT; ++t) {
-                  uint64_t m = I[t];
-                  while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int idx = min(max(gf - (t * 64 + b), 0), G);  // 0 = "at or after gf": contributes nothing
-                    tn += tabs[idx].x;
-                    ts += tsb[idx].x;
-                  }
-                  m = V[t];
-                  while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    ts += tsb[min(max(gf - (t * 64 + b), 0), G)].x;
-                  }
+                for (int k = 0; k < n_e; ++k) {
+                  const int e = epos[k];
+                  const int pos = e & 0x7FFF;
+                  const int idx = pos < gf ? gf - pos : 0;  // 0 = "at or after gf": contributes nothing
+                  if (!(e & 0x8000)) tn += tabs[idx].x;
+                  ts += tsb[idx].x;
                 }
               }
               cfn_hi = firstI < gf ? 0x3FF00000u : 0u;
               cfs_hi = min(firstI, firstV) < gf ? 0x3FF00000u : 0u;
-              inw = word_at(In, gf) >> (gf & 63);
-              vw = word_at(V, gf) >> (gf & 63);
+              next_i = ki < n_new ? (int)inl[ki * 64] : ABD_G2_NONE;
+              kv = 0;
+              for (int k = 0; k < n_v; ++k) kv += (int)vpos[k] < gf ? 1 : 0;
+              next_v = kv < n_v ? (int)vpos[kv] : ABD_G2_NONE;
               S = 0.0;
               g = g_first = gf;
               active = true;
@@ -560,10 +746,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       // ---- 2. one gap for every walking lane ----
       bool finished = false;
       if (active) {
-        const uint32_t ei_hi = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)inw, 0u, 1u) & 0x3FF00000u;
-        const uint32_t ev_hi = (uint32_t)__builtin_amdgcn_sbfe((int)(uint32_t)vw, 0u, 1u) & 0x3FF00000u;
-        inw >>= 1;
-        vw >>= 1;
+        const bool hit_i = g == next_i, hit_v = g == next_v;
+        const uint32_t ei_hi = hit_i ? 0x3FF00000u : 0u;
+        const uint32_t ev_hi = hit_v ? 0x3FF00000u : 0u;
         const double e_i = hi_to_double(ei_hi, z_ei), e_v = hi_to_double(ev_hi, z_ev);
         cfn_hi |= ei_hi;
         cfs_hi |= ei_hi | ev_hi;
@@ -574,6 +759,14 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         const YX<R> on = dataN[g], os = dataS[g];
         S += g2_term(an, (double)on.x, (double)on.y, p.c_n, p.d_n, p.nh_n, as, (double)os.x, (double)os.y, p.c_s, p.d_s, p.nh_s,
                      tab_e2);
+        if (hit_i) {
+          ++ki;
+          next_i = ki < n_new ? (int)inl[ki * 64] : ABD_G2_NONE;
+        }
+        if (hit_v) {
+          ++kv;
+          next_v = kv < n_v ? (int)vpos[kv] : ABD_G2_NONE;
+        }
         ++g;
         // every remaining term is <= 0: delta <= B0 + S; the factor keeps the test on the safe side of rounding
         const bool dead = fma(S, 1.0 - 1e-9, B0) < thr;
@@ -582,9 +775,6 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
           result[pidx] = (!dead && (delta > 0.0 || delta > lu)) ? ABD_G2_ACCEPT : ABD_G2_REJECT;
           active = false;
           finished = true;
-        } else if ((g & 63) == 0) {
-          inw = word_at(In, g);
-          vw = word_at(V, g);
         }
       }
       dirty |= __builtin_amdgcn_ballot_w64(finished) != 0;
@@ -600,25 +790,35 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       // (only walks that have already survived tail_age gaps: a young one is most likely rejected within a few more)
       const uint64_t old_walkers = __builtin_amdgcn_ballot_w64(active && g - g_first >= ga.tail_age);
       if (next >= n_prop && old_walkers != 0 && __builtin_popcountll(walking) <= ga.tail_lanes) {
-        const int L = __builtin_ctzll(old_walkers);
+        const int Lw = __builtin_ctzll(old_walkers);
         if (STATS) ++st_tail;
-        const int g_l = __builtin_amdgcn_readlane(g, L);
-        uint64_t In_l[ABD_MAXT], Is[ABD_MAXT], Vs[ABD_MAXT];
+        const int g_l = __builtin_amdgcn_readlane(g, Lw);
+        // the walker's infections from its gap on, as a row shifted down to that gap
+        uint64_t Is[MT], Vs[MT];
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t)
-          In_l[t] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(In[t] >> 32), L) << 32) |
-                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)In[t], L);
-        shift_row_down(In_l, g_l, Is);
-        shift_row_down(V, g_l, Vs);
-        const bool ci0 = __builtin_amdgcn_readlane((int)cfn_hi, L) != 0, civ0 = __builtin_amdgcn_readlane((int)cfs_hi, L) != 0;
-        double un[ABD_MAXT], us[ABD_MAXT], term[ABD_MAXT];
-        g2_eval_rounds<R>(a, p, lane, Is, Vs, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, un,
-                          us, term, g_l, readlane_f64(tn, L), readlane_f64(ts, L), ci0, civ0);
+        for (int t = 0; t < MT; ++t) Is[t] = 0;
+        {
+          const int k_l = __builtin_amdgcn_readlane(ki, Lw), n_l = __builtin_amdgcn_readlane(n_new, Lw);
+          const uint16_t* lst = inl - lane + Lw;
+          for (int k = k_l; k < n_l; ++k) {
+            const int rel = __builtin_amdgcn_readfirstlane((int)lst[k * 64]) - g_l;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+              if (t == (rel >> 6)) Is[t] |= 1ull << (rel & 63);
+          }
+          uint64_t V[MT];
+          g2_load_row<MT>(row_v, V);
+          shift_row_down<MT>(V, g_l, Vs);
+        }
+        const bool ci0 = __builtin_amdgcn_readlane((int)cfn_hi, Lw) != 0, civ0 = __builtin_amdgcn_readlane((int)cfs_hi, Lw) != 0;
+        double term[MT];
+        g2_eval_rounds<R, MT>(a, p, lane, Is, Vs, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2,
+                              term, g_l, readlane_f64(tn, Lw), readlane_f64(ts, Lw), ci0, civ0);
         double tsum = 0.0;
 #pragma unroll
-        for (int t = 0; t < ABD_MAXT; ++t) tsum += term[t];
+        for (int t = 0; t < MT; ++t) tsum += term[t];
         const double rest = wave_sum_uniform(tsum);
-        if (lane == L) {
+        if (lane == Lw) {
           const double delta = B0 + (S + rest);
           result[pidx] = (delta > 0.0 || delta > lu) ? ABD_G2_ACCEPT : ABD_G2_REJECT;
           active = false;
@@ -644,23 +844,43 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         const int d = __builtin_amdgcn_readfirstlane((int)plist[frontier]);
         bool accepted = rr == ABD_G2_ACCEPT;
         if (rr == ABD_G2_COMPLEX) {
-          // the waning flip changes rho_j at every gap: the whole wave evaluates the proposed state
-          const bool wn = !wj;
-          double un[ABD_MAXT], us[ABD_MAXT], term[ABD_MAXT];
-          g2_eval_rounds<R>(a, p, lane, I, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS, tab_e2,
-                            un, us, term);
+          // the whole wave evaluates the proposed state: the waning flip (rho_j changes at every gap), or an i_raw flip with
+          // more new infections than a lane holds
+          const bool wn = d == G ? !wj : wj;
+          uint64_t In[MT], V[MT];
+          g2_load_row<MT>(row_v, V);
+          double delta_prior;
+          if (d == G) {
+            g2_load_row<MT>(row_i, In);
+            delta_prior = wn ? theta7 : -theta7;  // Bernoulli(waner | p_waner) abd.py:373
+          } else {
+            uint64_t Rn[MT], P[MT], I0n[MT], none[MT];
+            g2_load_row<MT>(row_r, Rn);
+            g2_load_row<MT>(row_p, P);
+            bool was_one = false;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+              none[t] = 0;
+              if (t == (d >> 6)) {
+                was_one = ((Rn[t] >> (d & 63)) & 1ull) != 0;
+                Rn[t] ^= 1ull << (d & 63);
+              }
+            }
+            constrain_i0<MT>(Rn, P, a, I0n);
+            three_gaps_from<MT>(I0n, none, 0, In);
+            delta_prior = was_one ? -theta0 : theta0;
+          }
+          double term[MT];
+          g2_eval_rounds<R, MT>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS, tab_e2, term);
           double tsum = 0.0;
 #pragma unroll
-          for (int t = 0; t < ABD_MAXT; ++t) tsum += term[t];
-          const double delta = (wn ? theta7 : -theta7) + (wave_sum_uniform(tsum) - total_cur);  // Bernoulli(waner | p_waner) abd.py:373
-          const double log_u = readfirstlane_f64(log_uniform_u32(accw[G], tab_e2));
+          for (int t = 0; t < MT; ++t) tsum += term[t];
+          const double delta = delta_prior + (wave_sum_uniform(tsum) - total_cur);
+          const double log_u = readfirstlane_f64(log_uniform_u32(accw[d], tab_e2));
           accepted = delta > 0.0 || delta > log_u;
-          if (accepted) wj = wn;
-        } else if (accepted) {
-#pragma unroll
-          for (int t = 0; t < ABD_MAXT; ++t)
-            if (t == (d >> 6)) Rw[t] ^= 1ull << (d & 63);
+          if (accepted && d == G) wj = wn;
         }
+        if (accepted && d < G && lane == 0) row_r[d >> 6] ^= 1ull << (d & 63);
         frontier += 1;
         if (!accepted) continue;
         // the state has changed: everything evaluated beyond this proposal is void
@@ -668,26 +888,27 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         for (int e = frontier + lane; e < next; e += 64) result[e] = ABD_G2_PENDING;
         next = frontier;
         active = false;
+        __builtin_amdgcn_wave_barrier();
         refresh();
         break;
       }
     }
-    n_prop_total += (unsigned long long)frontier;
+    n_prop_total += (unsigned int)frontier;
 
     // ---- write the individual's state back: raw bits, waning flag, and what the slot keeps beside them (the
     // constrained words the evaluation kernels read, the changes of sum(i_raw) and sum(ab_s_waner)) ----
-    if (lane == 0) {
-#pragma unroll
-      for (int t = 0; t < ABD_MAXT; ++t)
-        if (t < nt) {
-          rw[(int64_t)t * N + j] = Rw[t];
-          iw[(int64_t)t * N + j] = I[t];
-        }
-      waner[j] = wj ? 1 : 0;
-    }
     int pc1 = wj ? (1 << 16) : 0;
+    {
+      uint64_t Rw[MT];
+      g2_load_row<MT>(row_r, Rw);
 #pragma unroll
-    for (int t = 0; t < ABD_MAXT; ++t) pc1 += __builtin_popcountll(Rw[t]);
+      for (int t = 0; t < MT; ++t) pc1 += __builtin_popcountll(Rw[t]);
+    }
+    if (lane < nt) {
+      rw[(int64_t)lane * N + j] = row_r[lane];
+      iw[(int64_t)lane * N + j] = row_i[lane];
+    }
+    if (lane == 0) waner[j] = wj ? 1 : 0;
     d_n1 += (pc1 & 0xFFFF) - (pc0 & 0xFFFF);
     d_m1 += (pc1 >> 16) - (pc0 >> 16);
     __builtin_amdgcn_wave_barrier();
@@ -698,8 +919,8 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     atomicAdd(cnt + 1, (unsigned long long)(long long)d_m1);
   }
   if (lane == 0 && (n_acc | n_prop_total)) {
-    atomicAdd(ga.counts + 2 * c + 0, n_acc);
-    atomicAdd(ga.counts + 2 * c + 1, n_prop_total);
+    atomicAdd(ga.counts + 2 * c + 0, (unsigned long long)n_acc);
+    atomicAdd(ga.counts + 2 * c + 1, (unsigned long long)n_prop_total);
   }
   if (STATS && lane == 0 && ga.stats) {
     atomicAdd(ga.stats + 0, st_inds);
@@ -709,6 +930,6 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     atomicAdd(ga.stats + 4, st_lane_steps);
     atomicAdd(ga.stats + 5, st_tail);
     atomicAdd(ga.stats + 6, st_commit);
-    atomicAdd(ga.stats + 7, n_acc);
+    atomicAdd(ga.stats + 7, (unsigned long long)n_acc);
   }
 }

@@ -133,7 +133,7 @@ def _ctx(coh, splits=None, ignore=False, n_chains=1, storage="f64"):
 
 @gpu
 @pytest.mark.parametrize("G,N,splits", [(20, 23, None), (70, 130, (30,)), (200, 64, (66, 133)), (256, 9, None), (5, 300, (2,)),
-                                        (300, 40, (100, 200)), (512, 11, None)])  # beyond 256 gaps: the 8-word wave-per-proposal kernel
+                                        (300, 40, (100, 200)), (512, 11, None), (257, 30, (0, 257))])  # beyond 256 gaps: 8 words per individual
 def test_gpu_sweep_matches_cpu_restatement_dense(G, N, splits):
     coh = oracle_cohort_from_synth(synthetic.make_cohort(N, G, seed=G + N))
     co = c_oracle.COracle(coh, splits)
@@ -157,6 +157,28 @@ def test_gpu_sweep_matches_cpu_restatement_dense(G, N, splits):
     lp, _ = ctx.logp_dlogp(1, thetas[1])
     ref = O.logp_dlogp(thetas[1], states[1][0], states[1][1], coh, splits)[0]
     assert abs(lp - ref) <= 1e-6 * abs(ref)
+
+
+@gpu
+@pytest.mark.parametrize("G,N,splits,rate", [(200, 40, None, 1.0), (300, 24, (100, 200), 1.0), (512, 9, (256,), 0.5), (64, 50, None, 0.9)])
+def test_gpu_sweep_dense_states_full_of_infections(G, N, splits, rate):
+    """Raw states with (nearly) every gap set: the kept infections are one in four gaps, far more than a lane of the
+    lane-per-proposal kernel holds for its walk (ABD_G2_KCAP) -- those proposals are evaluated by the whole wave at the
+    frontier.  Same trajectories as the CPU restatement, and as the wave-per-proposal kernel."""
+    coh = oracle_cohort_from_synth(synthetic.make_cohort(N, G, seed=3 * G + N))
+    co = c_oracle.COracle(coh, splits)
+    ctx = _ctx(coh, splits, n_chains=1)
+    theta, i_raw, w = _state(coh, 77, rate=rate)
+    ctx.set_discrete(0, i_raw, w)
+    for sweep in range(2):
+        acc, prop = ctx.gibbs_sweep([0], theta[None, :], seed=5, sweep=sweep)
+        i_ref, w_ref, a_ref, p_ref = co.gibbs_sweep(theta, i_raw, w, chain=0, seed=5, sweep=sweep)
+        i_gpu, w_gpu = ctx.get_discrete(0)
+        np.testing.assert_array_equal(i_gpu, i_ref)
+        np.testing.assert_array_equal(w_gpu, w_ref)
+        assert (int(acc[0]), int(prop[0])) == (a_ref, p_ref)
+        i_raw, w = i_ref, w_ref
+    ctx.close()
 
 
 @gpu

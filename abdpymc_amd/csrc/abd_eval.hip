@@ -456,9 +456,11 @@ int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* 
   a->prior_const = c->prior_const;
   a->xcd_remap = c->xcd_remap ? 1 : 0;
   a->service = any_fwd ? 1 : 0;
-  // the service workgroup takes a workgroup slot: a grid that fills the chip exactly gives it one of its own (the ranges are
-  // equal shares of the plane whatever their number), or the last range would only start when the first workgroup has left
-  if (a->service && any_step && blocks > 1 && blocks % c->n_cu == 0) blocks -= 1;
+  // the service workgroup takes a workgroup slot: a grid that fills the chip exactly leaves it one (the ranges are equal
+  // shares of the plane whatever their number), or the last range would only start when the first workgroup has left.
+  // ALWAYS, whether this launch carries a service workgroup or not: the split of the plane decides the order of the sums, and
+  // a chain's numbers must not depend on what its unit's other chains happen to have pending
+  if (any_step && blocks > 1 && blocks % c->n_cu == 0) blocks -= 1;
   a->G = c->G;
   a->N = c->N;
   a->n_lg = c->n_lg;

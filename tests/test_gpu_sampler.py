@@ -773,3 +773,40 @@ def test_set_adaptation_installs_step_size_and_metric(test_td):
         smp.set_adaptation(5, im, eps)
     smp.close()
     m.close()
+
+
+def test_train_units_of_several_chains_are_repeatable(monkeypatch):
+    """Dense cohort large enough for the units' full launch shape (a grid that fills the chip), chains in train units of 2 and
+    of 4: a chain's sweeps run on its own stream beside its unit's launches for the other chains, so which chains step in
+    which launch depends on timing -- a chain's draws must not (the launch shape, and with it the order of the sums, is the
+    unit's, whatever the other chains have pending).  Twice the same bits, no completion wait falling back."""
+    from abdpymc_amd._native import Context
+
+    N, G, C = 1500, 200, 4
+    sc = synthetic.make_cohort(N, G, seed=12)
+
+    def run(unit):
+        monkeypatch.setenv("ABD_SAMPLER_UNIT", unit)
+        ctx = Context(G, N, sc.s_obs, sc.n_obs, sc.vacs, sc.pcrpos, n_chains=C)
+        for c in range(C):
+            ctx.set_discrete(c, *synthetic.make_chain_state(N, G, c))
+        th0 = np.stack([synthetic.make_thetas(G, 1, c)[0] for c in range(C)])
+        smp = ctx.sampler(np.arange(C), th0, tune=10, seed=3)
+        th, st = smp.run(16)
+        states = [ctx.get_discrete(c) for c in range(C)]
+        fb = ctx.wait_fallbacks
+        smp.close()
+        ctx.close()
+        return th, st, states, fb
+
+    for unit in ("2", "4"):
+        a, b = run(unit), run(unit)
+        assert a[3] == 0 and b[3] == 0
+        np.testing.assert_array_equal(a[0], b[0])
+        for k in a[1]:
+            if k != "t_done":
+                np.testing.assert_array_equal(a[1][k], b[1][k], err_msg=k)
+        for (i0, w0), (i1, w1) in zip(a[2], b[2]):
+            np.testing.assert_array_equal(i0, i1)
+            np.testing.assert_array_equal(w0, w1)
+        assert np.isfinite(a[0]).all() and (a[1]["n_steps"] >= 1).all() and a[1]["gibbs_proposed"].min() > 0

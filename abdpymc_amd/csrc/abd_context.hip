@@ -91,6 +91,23 @@ ConstrainArgs constrain_args(const abd_ctx* c) {
   return a;
 }
 
+#ifdef ABD_STAMPS
+unsigned long long* stamps_buffer() {
+  static unsigned long long* stamps = nullptr;
+  if (!stamps) {
+    (void)hipHostMalloc((void**)&stamps, 4096 * 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+    if (const char* e = std::getenv("ABD_STAMPS_PTR_OUT")) {  // the probe reads the buffer through its address
+      FILE* f = std::fopen(e, "w");
+      if (f) {
+        std::fprintf(f, "%llu\n", (unsigned long long)(uintptr_t)stamps);
+        std::fclose(f);
+      }
+    }
+  }
+  return stamps;
+}
+#endif
+
 void base_args(const abd_ctx* c, EvalArgs& a) {
   std::memset(&a, 0, sizeof a);
   a.y_n = c->n.y;
@@ -124,18 +141,7 @@ void base_args(const abd_ctx* c, EvalArgs& a) {
   a.pw = c->ignore_pcr ? nullptr : c->pw;
   a.exp2_tab = c->exp2_tab;
 #ifdef ABD_STAMPS
-  {
-    static unsigned long long* stamps = nullptr;
-    if (!stamps) (void)hipHostMalloc((void**)&stamps, 4096 * 16 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
-    a.stamps = stamps;
-    if (const char* e = std::getenv("ABD_STAMPS_PTR_OUT")) {  // the probe reads the buffer through its address
-      FILE* f = std::fopen(e, "w");
-      if (f) {
-        std::fprintf(f, "%llu\n", (unsigned long long)(uintptr_t)stamps);
-        std::fclose(f);
-      }
-    }
-  }
+  a.stamps = stamps_buffer();
 #endif
   a.G = c->G;
   a.N = c->N;

@@ -563,7 +563,7 @@ __device__ __forceinline__ void train_epilogue(const EvalArgs& a, double* sm, in
 __host__ __device__ inline size_t abd_dense_lds(int G, int cb, bool xc = false, bool train = false) {
   const size_t need = (size_t)cb * 2 * (size_t)(G + 1) * sizeof(double2_t) + (size_t)ABD_WAVES_PER_BLOCK * ABD_NOUT * sizeof(double) +
                       (size_t)ABD_EXP2_TAB * sizeof(double) + (xc ? (size_t)2 * ABD_XDICT * sizeof(double) : 0);
-  const size_t fin = train ? (size_t)ABD_TRAIN_CB * ABD_TRAIN_SM * sizeof(double) : (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double);
+  const size_t fin = (size_t)ABD_FIN_PARTS * ABD_NOUT * sizeof(double) + (train ? (size_t)ABD_TRAIN_CB * ABD_TRAIN_SM * sizeof(double) : 0);
   return need > fin ? need : fin;
 }
 
@@ -830,6 +830,38 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     // one shard row and counts in at the top; the top's last arriver sums the shard rows (in shard order) and runs the
     // chains' state machines, wave k chain k's (abd_train.hpp).  Fixed orders: the sums depend on the launch shape only.
     // Hand-off as above: rows stored write-through by wave 0, drained, then the returning agent-scope add; re-read with sc1 loads.
+    // (a launch of at most ABD_TRAIN_ONE_LEVEL workgroups -- one per CU: a unit of one chain -- counts in at the top directly and
+    // its last workgroup sums all rows, 256 threads wide: one hop less on the path every leapfrog of the chain waits for)
+    if (nblk <= ABD_TRAIN_ONE_LEVEL) {
+      if (wave == 0) {
+        handoff_drain_stores();
+        if (lane == 0) {
+          const unsigned int old = handoff_count_in(a.fin_count);
+          flag[0] = old + 1u == (unsigned int)nblk ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      const bool last1 = flag[0] != 0;
+      __syncthreads();
+      if (!last1) return;
+      ABD_STAMP(10);
+      handoff_acquire();
+      double* sm = reinterpret_cast<double*>(smem);
+      double* sm_chain1 = sm + ABD_FIN_PARTS * ABD_NOUT;  // [CB][ABD_TRAIN_SM] behind the sum's scratch
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+        if (a.tc[cc].action == ABD_TR_STEP) {  // (workgroup-uniform)
+          sum_chain_coherent<ABD_BLOCK>(a.partials + (int64_t)cc * nblk * ABD_NOUT, nblk, sm, tid);
+          if (tid < ABD_NOUT) sm_chain1[cc * ABD_TRAIN_SM + tid] = sm[tid];
+          __syncthreads();
+        }
+      }
+      ABD_STAMP(11);
+      if (wave < CB && a.tc[wave].action != ABD_TR_SKIP) train_step(a, a.tc[wave], sm_chain1 + wave * ABD_TRAIN_SM, lane);
+      ABD_STAMP(12);
+      if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     const int shard = blk % ABD_TRAIN_SHARDS;
     const int n_in_shard = (nblk - shard + ABD_TRAIN_SHARDS - 1) / ABD_TRAIN_SHARDS;
     const int n_shards = min(nblk, ABD_TRAIN_SHARDS);

@@ -467,7 +467,7 @@ int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* 
   a->K_n = (int32_t)c->n.K;
   a->K_s = (int32_t)c->s.K;
 #ifdef ABD_STAMPS
-  a->stamps = nullptr;
+  a->stamps = stamps_buffer();
 #endif
   range_split(c, blocks, ABD_WAVES_PER_BLOCK / cb, *a, false);
   const size_t lds = abd_dense_lds(c->G, cb, xc, true);

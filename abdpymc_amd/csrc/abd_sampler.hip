@@ -54,7 +54,10 @@ struct abd_sampler {
     TrainBegin* begin_h = nullptr;   // mapped host memory [kBeginBlocks]
     TrainBegin* begin_d = nullptr;
     hipStream_t side = nullptr;      // the chain's sweep and its recording kernels
-    hipEvent_t sweep_done = nullptr;
+    // mapped host memory: [0], [1] the sweep's accepted / proposed counts, [2] (as a double) the tag of the sweep they belong to
+    unsigned long long* done_h = nullptr;
+    unsigned long long* done_d = nullptr;
+    double sweep_tag = 0.0;          // tag of the chain's last sweep (1, 2, 3, ...)
     int64_t n_rec = 0;               // records the steps queued so far produce (index of the next one)
     int64_t n_begin = 0;             // transitions handed over so far
   };
@@ -63,6 +66,18 @@ struct abd_sampler {
 };
 
 namespace {
+
+// The end of a chain's sweep as the native sampler's host thread sees it (abd_sampler.hip): the sweep's two counters go to
+// mapped host memory and a tag behind them -- polled with a plain memory read (a hipEventQuery per pass of the host's loop
+// costs the loop several microseconds for as long as a sweep is running, and every chain's records wait behind it)
+__global__ void abd_sweep_done_kernel(const unsigned long long* counts, unsigned long long* host_counts, double* host_tag, double tag) {
+  if (threadIdx.x == 0) {
+    host_counts[0] = counts[0];
+    host_counts[1] = counts[1];
+    __threadfence_system();
+    __hip_atomic_store(host_tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 void train_free(abd_sampler* s) {
   for (auto& t : s->tu) {
@@ -89,7 +104,7 @@ void dtrain_free(abd_sampler* s) {
     if (d.st) (void)hipFree(d.st);
     if (d.ring_h) (void)hipHostFree(d.ring_h);
     if (d.begin_h) (void)hipHostFree(d.begin_h);
-    if (d.sweep_done) (void)hipEventDestroy(d.sweep_done);
+    if (d.done_h) (void)hipHostFree(d.done_h);
     if (d.side) (void)hipStreamDestroy(d.side);
   }
   s->dc.clear();
@@ -107,7 +122,9 @@ int dtrain_alloc(abd_sampler* s) {
     std::memset(d.begin_h, 0, abd_sampler::kBeginBlocks * sizeof(TrainBegin));
     HIP_TRY(hipHostGetDevicePointer((void**)&d.begin_d, d.begin_h, 0));
     HIP_TRY(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&d.sweep_done, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&d.done_h, 4 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(d.done_h, 0, 4 * sizeof(unsigned long long));
+    HIP_TRY(hipHostGetDevicePointer((void**)&d.done_d, d.done_h, 0));
   }
   HIP_TRY(hipDeviceSynchronize());
   return ABD_OK;
@@ -798,8 +815,8 @@ int sampler_run_trains(abd_sampler* s, int64_t n_iter, double* theta, double* st
       o[ABD_STAT_DIVERGING] = nu.stats.diverging ? 1.0 : 0.0;
       o[ABD_STAT_ENERGY] = nu.stats.energy;
       o[ABD_STAT_MAX_ENERGY_ERROR] = nu.stats.max_energy_error;
-      o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j] : 0.0;
-      o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)c->h_counts_chain[2 * (size_t)j + 1] : 0.0;
+      o[ABD_STAT_GIBBS_ACCEPTED] = with_counts ? (double)d.done_h[0] : 0.0;
+      o[ABD_STAT_GIBBS_PROPOSED] = with_counts ? (double)d.done_h[1] : 0.0;
       o[ABD_STAT_T_DONE] = std::chrono::duration<double>(clk::now() - t_begin).count();
     }
     // running sums and the draw's record: on the chain's own stream, behind its sweep and in front of the next one (they read
@@ -836,9 +853,10 @@ int sampler_run_trains(abd_sampler* s, int64_t n_iter, double* theta, double* st
       if (int rc = enqueue_gibbs(c, 1, &id, s->ch[(size_t)j].nuts.q, (s->o.seed << 20) ^ 0x5EEDull, (uint32_t)(s->it + r.k), (uint32_t)s->o.chain_offset,
                                  d.side, c->d_counts_chain + 2 * (size_t)j, c->d_work + c->n_slots + j, nullptr))
         return rc;
-      HIP_TRY(hipMemcpyAsync(c->h_counts_chain + 2 * (size_t)j, c->d_counts_chain + 2 * (size_t)j, 2 * sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost, d.side));
-      HIP_TRY(hipEventRecord(d.sweep_done, d.side));
+      d.sweep_tag += 1.0;
+      hipLaunchKernelGGL(abd_sweep_done_kernel, dim3(1), dim3(64), 0, d.side, c->d_counts_chain + 2 * (size_t)j, d.done_d,
+                         reinterpret_cast<double*>(d.done_d + 2), d.sweep_tag);
+      HIP_TRY(hipGetLastError());
       r.state = SWEEP;
       return ABD_OK;
     }
@@ -899,12 +917,9 @@ int sampler_run_trains(abd_sampler* s, int64_t n_iter, double* theta, double* st
       for (int j = lo; j < hi; ++j) {
         Run& r = runs[(size_t)j];
         if (r.state != SWEEP) continue;
-        const hipError_t qe = hipEventQuery(s->dc[(size_t)j].sweep_done);
-        if (qe == hipErrorNotReady) continue;
-        if (qe != hipSuccess) {
-          rc_loop = fail(ABD_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(qe));
-          break;
-        }
+        const abd_sampler::DChain& dj = s->dc[(size_t)j];
+        if (*reinterpret_cast<volatile const double*>(dj.done_h + 2) != dj.sweep_tag) continue;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         progressed = true;
         const bool last = r.k + 1 == n_iter;
         if (!last) s->ch[(size_t)j].begin_draw();

@@ -103,6 +103,7 @@ struct TrainArgs {
 #define ABD_TRAIN_CB 4      // chains per unit at most (= waves of a workgroup: wave k of the last workgroup runs chain k's state machine)
 #define ABD_TRAIN_RING 64   // records per chain in mapped host memory
 #define ABD_TRAIN_SHARDS 32      // a train launch's workgroups count in in shards (abd_dense.hpp: dense_body) ...
+#define ABD_TRAIN_ONE_LEVEL 256  // ... unless the launch has at most this many: then one counter, and its last workgroup sums every row
 #define ABD_TRAIN_CNT_STRIDE 32  // ... whose counters lie 128 bytes apart: [0] the top, [(1 + s) * stride] shard s
 enum { ABD_TR_SKIP = 0, ABD_TR_STEP = 1, ABD_TR_BEGIN = 2 };  // what a launch does with a chain of its unit
 enum { ABD_PH_IDLE = 0, ABD_PH_EVAL0 = 1, ABD_PH_LEAF = 2 };  // TrainChain::phase

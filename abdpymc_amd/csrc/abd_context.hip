@@ -61,17 +61,7 @@ void assemble(const abd_ctx* c, const HostTerms& h, const double* t, const doubl
 
 ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr) {
   ChainPar p;
-  p.perm_n = tr.perm_n;
-  p.temp_n = tr.temp_n;
-  p.rho_n = tr.rho_n;
-  p.init_n = tr.init_n;
-  p.perm_s = tr.perm_s;
-  p.rho_s = tr.rho_s;
-  p.init_s = tr.init_s;
-  p.b_n = tr.b_n;
-  p.d_n = tr.d_n;
-  p.b_s = tr.b_s;
-  p.d_s = tr.d_s;
+  chain_par_from_tr(p, &tr.p);
   p.rw = c->slots[chain].rw;
   p.waner = c->slots[chain].waner;
   p.iw = c->slots[chain].iw;
@@ -648,11 +638,15 @@ int abd_create(const abd_desc* d, abd_ctx** out) {
   CREATE_TRY(hipMalloc(&c->d_fin_count, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
   CREATE_TRY(hipMemset(c->d_fin_count, 0, (size_t)kMaxPipes * ABD_MAX_BATCH * sizeof(unsigned int)));
   {
-    const size_t tc_bytes = (size_t)kMaxPipes * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE * sizeof(unsigned int);
+    const size_t tc_bytes = (size_t)kMaxPipes * ABD_MAX_BATCH * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE * sizeof(unsigned int);
     CREATE_TRY(hipMalloc(&c->d_train_count, tc_bytes));
     CREATE_TRY(hipMemset(c->d_train_count, 0, tc_bytes));
   }
   c->dense_own_sum = env_int("ABD_DENSE_OWN_SUM", 1) != 0;
+  // measured (round 4, profiles/r04: sync_own_sum_ab.txt): 28.8 / 33.8 / 43.1 us per call of 1 / 2 / 4 chains at config 3 with the
+  // launch summing its own rows (two-level count-in at 1 024 workgroups), 28.1 / 32.0 / 41.9 us with the sum as a second
+  // launch: the second launch stays
+  c->sync_own_sum = c->dense_own_sum && tune_int("ABD_SYNC_OWN_SUM", 0) != 0;
   CREATE_TRY(hipHostMalloc(&c->h_counts_chain, (size_t)c->n_slots * 2 * sizeof(unsigned long long), hipHostMallocDefault));
   c->gibbs_v1 = env_int("ABD_GIBBS_V1", 0) != 0;
   c->g2_refill_min = std::max(1, std::min(64, tune_int("ABD_G2_REFILL_MIN", ABD_G2_REFILL_MIN)));

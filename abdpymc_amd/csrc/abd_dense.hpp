@@ -580,6 +580,79 @@ struct is_train_args<DenseTrainArgs> {
 __device__ __forceinline__ void train_service(const DenseTrainArgs& a, int wave, int lane);
 __device__ __forceinline__ void train_step(const DenseTrainArgs& a, const TrainChainArgs& tc, double* sm, int lane);
 
+// Count-in in two levels and the fixed-order sums of a launch's partial rows (see dense_body).  rows: [CB][nblk][ABD_NOUT] partial
+// rows of this workgroup's CB chains, this workgroup's already stored write-through by wave 0 in front of a workgroup barrier;
+// shard_rows: [CB][ABD_TRAIN_SHARDS][ABD_NOUT]; cnt: [0] the top counter, [(1 + s) * ABD_TRAIN_CNT_STRIDE] shard s (all zero between
+// launches); mask: bit cc = chain cc has rows to sum.  Returns true in ONE workgroup of the launch -- the one whose count came
+// last at the top -- with chain cc's 16 sums in sm_chain[cc * ABD_TRAIN_SM ..]; every other workgroup gets false and is done.
+// flag: one int of LDS.  Fixed orders (a shard's rows in range order, the shards in order): the sums depend on nblk only.
+template <int CB>
+__device__ __forceinline__ bool two_level_sums(const double* rows, double* shard_rows, unsigned int* cnt, int nblk, int blk, unsigned int mask,
+                                               int* flag, double* sm_chain, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int shard = blk % ABD_TRAIN_SHARDS;
+  const int n_in_shard = (nblk - shard + ABD_TRAIN_SHARDS - 1) / ABD_TRAIN_SHARDS;
+  const int n_shards = min(nblk, ABD_TRAIN_SHARDS);
+  unsigned int* cnt_shard = cnt + (1 + shard) * ABD_TRAIN_CNT_STRIDE;
+  if (wave == 0) {
+    handoff_drain_stores();
+    if (lane == 0) {
+      const unsigned int old = handoff_count_in(cnt_shard);
+      flag[0] = old + 1u == (unsigned int)n_in_shard ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const bool shard_last = flag[0] != 0;
+  __syncthreads();
+  if (!shard_last) return false;
+  handoff_acquire();
+  if (wave == 0) {
+    if (lane < CB * ABD_NOUT) {
+      const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
+      double v = 0.0;
+      if ((mask >> cc) & 1u) {
+        const double* col = rows + ((int64_t)cc * nblk + shard) * ABD_NOUT + k;
+        for (int i0 = 0; i0 < n_in_shard; i0 += 8) {
+          double q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            q[u] = i0 + u < n_in_shard ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_TRAIN_SHARDS * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v += q[u];
+        }
+      }
+      __hip_atomic_store(shard_rows + ((int64_t)cc * ABD_TRAIN_SHARDS + shard) * ABD_NOUT + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    handoff_drain_stores();
+    if (lane == 0) {
+      __hip_atomic_store(cnt_shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch that uses these counters)
+      const unsigned int old = handoff_count_in(cnt);
+      flag[0] = old + 1u == (unsigned int)n_shards ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const bool last = flag[0] != 0;
+  __syncthreads();
+  if (!last) return false;
+  handoff_acquire();
+  if (wave == 0 && lane < CB * ABD_NOUT) {
+    const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
+    const double* col = shard_rows + (int64_t)cc * ABD_TRAIN_SHARDS * ABD_NOUT + k;
+    double v = 0.0;
+    for (int i0 = 0; i0 < n_shards; i0 += 8) {
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = i0 + u < n_shards ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += q[u];
+    }
+    sm_chain[cc * ABD_TRAIN_SM + k] = v;
+  }
+  if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return true;
+}
+
 // The kernel's body for both of its entry points: abd_dense_kernel (EvalArgs: the chains' constants arrive in the kernel
 // arguments, the sums go back to the host) and abd_train_kernel (DenseTrainArgs: a leapfrog-train launch -- the constants
 // of a chain are those of the point its TrainChain holds, and the launch's last workgroup runs the chains' state machines).
@@ -627,18 +700,7 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
     p.perm_n = p.temp_n = p.rho_n = p.init_n = p.perm_s = p.rho_s = p.init_s = p.b_n = p.d_n = p.b_s = p.d_s = 0.0;
     if (chain_on) {
       // the point was left in device memory by the launch before this one on the stream (abd_terms.hpp: Transformed)
-      const double* tr = tc.st->pt[tc.use_slot].tr;
-      p.perm_n = tr[1];
-      p.temp_n = tr[2];
-      p.rho_n = tr[3];
-      p.init_n = tr[4];
-      p.perm_s = tr[5];
-      p.rho_s = tr[6];
-      p.init_s = tr[10];
-      p.b_n = tr[11];
-      p.d_n = tr[12];
-      p.b_s = tr[14];
-      p.d_s = tr[15];
+      abdi::chain_par_from_tr(p, tc.st->pt[tc.use_slot].tr);
     }
   } else {
     p = a.ch[cbase + c];
@@ -802,7 +864,7 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
   if ((lane & 3) == 0) red[wave * ABD_NOUT + reduce16_index(lane)] = tot;
   __syncthreads();
   bool own_sum = TRAINK;  // does the launch sum its own partial rows?
-  if constexpr (!TRAINK) own_sum = a.fin_count != nullptr;
+  if constexpr (!TRAINK) own_sum = a.fin_count != nullptr || a.fin_count2 != nullptr;
   if (tid < CB * ABD_NOUT) {
     const int cc = tid / ABD_NOUT, k = tid % ABD_NOUT;
     double v = 0.0;
@@ -862,69 +924,29 @@ __device__ __forceinline__ void dense_body(const ARGS& a) {
       if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    const int shard = blk % ABD_TRAIN_SHARDS;
-    const int n_in_shard = (nblk - shard + ABD_TRAIN_SHARDS - 1) / ABD_TRAIN_SHARDS;
-    const int n_shards = min(nblk, ABD_TRAIN_SHARDS);
-    unsigned int* cnt_shard = a.fin_count + (1 + shard) * ABD_TRAIN_CNT_STRIDE;
-    double* shard_rows = a.partials + (int64_t)CB * nblk * ABD_NOUT;  // [CB][ABD_TRAIN_SHARDS][ABD_NOUT]
-    if (wave == 0) {
-      handoff_drain_stores();
-      if (lane == 0) {
-        const unsigned int old = handoff_count_in(cnt_shard);
-        flag[0] = old + 1u == (unsigned int)n_in_shard ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    const bool shard_last = flag[0] != 0;
-    __syncthreads();
-    if (!shard_last) return;
-    handoff_acquire();
-    if (wave == 0) {
-      if (lane < CB * ABD_NOUT) {
-        const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
-        double v = 0.0;
-        if (a.tc[cc].action == ABD_TR_STEP) {
-          const double* col = a.partials + ((int64_t)cc * nblk + shard) * ABD_NOUT + k;
-          for (int i0 = 0; i0 < n_in_shard; i0 += 8) {
-            double q[8];
+    unsigned int step_mask = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              q[u] = i0 + u < n_in_shard ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_TRAIN_SHARDS * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += q[u];
-          }
-        }
-        __hip_atomic_store(shard_rows + ((int64_t)cc * ABD_TRAIN_SHARDS + shard) * ABD_NOUT + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      handoff_drain_stores();
-      if (lane == 0) {
-        __hip_atomic_store(cnt_shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch on this stream)
-        const unsigned int old = handoff_count_in(a.fin_count);
-        flag[0] = old + 1u == (unsigned int)n_shards ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    const bool last = flag[0] != 0;
-    __syncthreads();
-    if (!last) return;
-    handoff_acquire();
+    for (int cc = 0; cc < CB; ++cc) step_mask |= a.tc[cc].action == ABD_TR_STEP ? 1u << cc : 0u;
     double* sm_chain = reinterpret_cast<double*>(smem);  // [CB][ABD_TRAIN_SM]
-    if (wave == 0 && lane < CB * ABD_NOUT) {
-      const int cc = lane / ABD_NOUT, k = lane % ABD_NOUT;
-      const double* col = shard_rows + (int64_t)cc * ABD_TRAIN_SHARDS * ABD_NOUT + k;
-      double v = 0.0;
-      for (int i0 = 0; i0 < n_shards; i0 += 8) {
-        double q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = i0 + u < n_shards ? __hip_atomic_load(col + (int64_t)(i0 + u) * ABD_NOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v += q[u];
-      }
-      sm_chain[cc * ABD_TRAIN_SM + k] = v;
-    }
-    __syncthreads();
+    if (!two_level_sums<CB>(a.partials, a.partials + (int64_t)CB * nblk * ABD_NOUT, a.fin_count, nblk, blk, step_mask, flag, sm_chain, tid)) return;
     if (wave < CB && a.tc[wave].action != ABD_TR_SKIP) train_step(a, a.tc[wave], sm_chain + wave * ABD_TRAIN_SM, lane);
-    if (tid == 0) __hip_atomic_store(a.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (a.fin_count2 != nullptr) {
+    // a synchronous call's launch (a grid that fills the chip: 1 024 workgroups): counted in in two levels like a train launch;
+    // the workgroup that comes last writes each chain's row -- 15 sums, the tag behind a system-scope fence -- for the host
+    double* sm_chain = reinterpret_cast<double*>(smem);
+    const int n_rows_chains = (int)gridDim.y * CB;  // chains of the launch: the shard rows lie behind all partial rows
+    if (!two_level_sums<CB>(a.partials + (int64_t)cbase * nblk * ABD_NOUT,
+                            a.partials + ((int64_t)n_rows_chains * nblk + (int64_t)cbase * ABD_TRAIN_SHARDS) * ABD_NOUT,
+                            a.fin_count2 + (int64_t)blockIdx.y * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE, nblk, blk, (1u << CB) - 1u, flag,
+                            sm_chain, tid))
+      return;
+    if (wave == 0) {
+      if (lane < CB * ABD_NOUT && lane % ABD_NOUT < ABD_NOUT - 1)
+        a.fin_out[(int64_t)(cbase + lane / ABD_NOUT) * ABD_NOUT + lane % ABD_NOUT] = sm_chain[(lane / ABD_NOUT) * ABD_TRAIN_SM + lane % ABD_NOUT];
+      __threadfence_system();
+      __builtin_amdgcn_wave_barrier();
+      if (lane < CB) __hip_atomic_store(a.fin_out + (int64_t)(cbase + lane) * ABD_NOUT + (ABD_NOUT - 1), a.fin_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   } else {
     if (wave == 0) {
       handoff_drain_stores();

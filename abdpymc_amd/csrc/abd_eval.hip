@@ -151,7 +151,7 @@ int flush_pending(abd_ctx* c) {
 // Enqueue the evaluation of `n` chains (n <= ABD_MAX_BATCH); their sums go to rows d_out_rows[0..n).
 int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta, bool grad, double* d_out_rows,
                   bool deferred = false, int force_pipe = -1, const HostTerms* host = nullptr, double* seqp = nullptr,
-                  TrainArgs* train = nullptr) {
+                  TrainArgs* train = nullptr, bool sync_call = false) {
   // completion tags: the context's sequence, or the caller's own (a sampler unit handled by its own host thread: its
   // result rows are private, so its tags only have to be unique among themselves)
   double& seq = seqp ? *seqp : c->seq;
@@ -202,7 +202,10 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     if (int frc = flush_pipe(c, pi)) return frc;  // a train launch sums its own rows: nothing may be pending on its pipe
   // (the observation-lane kernel sums its own rows only in a train launch: for an evaluation the host waits for, the second
   // launch is as fast -- profiles/README.md, history)
-  const bool fused_sum = force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on) && ((c->dense && !lanes) || (lanes && train));
+  // (a synchronous call's dense launch too: the host waits for nothing but its rows, and a second launch is 3.6 us of it)
+  const bool sync_own = sync_call && c->sync_own_sum && c->dense && !lanes && !pp.on && c->timing == 0 &&
+                        (int64_t)n * (blocks + ABD_TRAIN_SHARDS) <= (int64_t)c->n_slots * c->blocks_max;
+  const bool fused_sum = (sync_own || (force_pipe >= 0 && c->dense_own_sum && !(c->fuse_finalize && pp.on))) && ((c->dense && !lanes) || (lanes && train));
   if (train) {
     if (!fused_sum || n != 1) return fail(ABD_ERR_STATE, "internal: a leapfrog-train launch needs one chain and a kernel that sums its own rows");
     train->dense = c->dense ? 1 : 0;
@@ -210,7 +213,10 @@ int enqueue_group(abd_ctx* c, int n, const int32_t* chains, const double* theta,
     a.train = *train;
   }
   if (fused_sum) {
-    a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
+    if (c->dense && !lanes && blocks > ABD_TRAIN_ONE_LEVEL)  // a grid that fills the chip: two-level count-in (abd_dense.hpp)
+      a.fin_count2 = c->d_train_count + (size_t)pi * ABD_MAX_BATCH * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE;
+    else
+      a.fin_count = c->d_fin_count + (size_t)pi * ABD_MAX_BATCH;
     a.fin_out = d_out_rows;
     a.fin_tag = seq + 1.0;
   }
@@ -354,7 +360,7 @@ int wait_slot(abd_ctx* c, int slot) {
 }
 
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred,
-                 int force_pipe, double* seqp) {
+                 int force_pipe, double* seqp, bool sync_call) {
   if (slot < 0 || slot >= kSyncSlot + c->n_sync_slots) return fail(ABD_ERR_ARG, "result slot %d outside [0, %d)", slot, kResultSlots);
   int rc = check_chains(c, n, chains);
   if (rc) return rc;
@@ -373,7 +379,7 @@ int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const doubl
   for (int k0 = 0; k0 < n; k0 += ABD_MAX_BATCH) {
     const int m = std::min(ABD_MAX_BATCH, n - k0);
     rc = enqueue_group(c, m, chains + k0, theta + (size_t)k0 * ABD_N_THETA, grad, rows + (size_t)k0 * ABD_NOUT, deferred, force_pipe,
-                       r.host.data() + k0, seqp);
+                       r.host.data() + k0, seqp, nullptr, sync_call);
     if (!rc && force_pipe >= 0) rc = flush_pipe(c, force_pipe);  // a group's fixed-order sum follows on its own stream
     if (rc) return rc;
   }
@@ -450,7 +456,7 @@ int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* 
     if (int frc = flush_pipe(c, pi)) return frc;  // (a pending fixed-order sum of an earlier plain launch on this stream)
   if (pi > 0) pp.busy = true;
   a->partials = pp.partials[0];
-  a->fin_count = c->d_train_count + (size_t)pi * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE;
+  a->fin_count = c->d_train_count + (size_t)pi * ABD_MAX_BATCH * (1 + ABD_TRAIN_SHARDS) * ABD_TRAIN_CNT_STRIDE;
   if ((int64_t)cb * (blocks + ABD_TRAIN_SHARDS) > (int64_t)c->n_slots * c->blocks_max)
     return fail(ABD_ERR_STATE, "internal: train launch of %d x %d workgroups exceeds the partial rows", cb, blocks);
   a->prior_const = c->prior_const;
@@ -566,9 +572,9 @@ int abd_logp_dlogp_many(abd_ctx* c, int32_t n_steps, int32_t n, const int32_t* c
 int abd_logp_dlogp_batch(abd_ctx* c, int32_t n, const int32_t* chains, const double* theta, double* logp, double* grad) {
   if (!c || !chains || !theta || !logp || !grad) return fail(ABD_ERR_ARG, "NULL argument");
   if (int frc = flush_ring(c)) return frc;
-  int rc = enqueue_slot(c, kSyncSlot, n, chains, theta, true);
+  int rc = enqueue_slot(c, kSyncSlot, n, chains, theta, true, false, -1, nullptr, true);
   if (rc) return rc;
-  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
+  if (int prc = flush_pending(c)) return prc;  // (a launch that did not sum its own rows: the sum follows right away)
   if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
   return fetch_slot(c, kSyncSlot, logp, grad);
 }
@@ -579,18 +585,18 @@ int abd_logp_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* logp,
 
 int abd_loglik_dlogp(abd_ctx* c, int32_t chain, const double* theta, double* loglik, double* grad) {
   if (!c || !theta || !loglik || !grad) return fail(ABD_ERR_ARG, "NULL argument");
-  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, true);
+  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, true, false, -1, nullptr, true);
   if (rc) return rc;
-  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
+  if (int prc = flush_pending(c)) return prc;
   if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
   return fetch_slot(c, kSyncSlot, loglik, grad, false);
 }
 
 int abd_logp(abd_ctx* c, int32_t chain, const double* theta, double* logp) {
   if (!c || !theta || !logp) return fail(ABD_ERR_ARG, "NULL argument");
-  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, false);
+  int rc = enqueue_slot(c, kSyncSlot, 1, &chain, theta, false, false, -1, nullptr, true);
   if (rc) return rc;
-  if (int prc = flush_pending(c)) return prc;  // a synchronous call sums its own partials right away
+  if (int prc = flush_pending(c)) return prc;
   if (int wrc = wait_rows(c, kSyncSlot, c->results[kSyncSlot].n, c->seq)) return wrc;
   return fetch_slot(c, kSyncSlot, logp, nullptr);
 }

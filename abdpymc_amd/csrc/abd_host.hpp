@@ -163,7 +163,8 @@ struct abd_ctx {
   // unchanged with 4
   bool dense_own_sum = true;
   unsigned int* d_fin_count = nullptr;  // [kMaxPipes][ABD_MAX_BATCH] zeroed counters of that sum
-  unsigned int* d_train_count = nullptr;  // [kMaxPipes][1 + ABD_TRAIN_SHARDS][ABD_TRAIN_CNT_STRIDE] zeroed counters of train launches (abd_dense.hpp)
+  unsigned int* d_train_count = nullptr;  // [kMaxPipes][ABD_MAX_BATCH][1 + ABD_TRAIN_SHARDS][ABD_TRAIN_CNT_STRIDE] zeroed counters of the two-level count-in (abd_dense.hpp: train launches use row 0 of their pipe, synchronous calls one row per grid row)
+  bool sync_own_sum = false;  // tuning build only: a synchronous call's dense launch sums its own partial rows (measured slower than the second launch)
   uint32_t ind_offset = 0;  // global index of this context's first individual (Gibbs random streams)
   bool xcd_remap = true;
   int fin_rows = 2;
@@ -229,7 +230,7 @@ int flush_pending(abd_ctx* c);
 int flush_ring(abd_ctx* c);
 int wait_rows(abd_ctx* c, int slot, int n, double tag, hipStream_t st = nullptr);
 int enqueue_slot(abd_ctx* c, int slot, int n, const int32_t* chains, const double* theta, bool grad, bool deferred = false,
-                 int force_pipe = -1, double* seqp = nullptr);
+                 int force_pipe = -1, double* seqp = nullptr, bool sync_call = false);
 int fetch_slot(abd_ctx* c, int slot, double* logp, double* grad, bool with_priors = true);
 int enqueue_train_launch(abd_ctx* c, int chain, int pi, TrainArgs* t, const HostTerms& first_terms, double* seqp = nullptr);
 int enqueue_dense_train(abd_ctx* c, int pi, int cb, int blocks, DenseTrainArgs* a);

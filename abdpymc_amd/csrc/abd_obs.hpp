@@ -61,18 +61,7 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_obs_kernel(const EvalArgs a) {
   // leapfrog trains (abd_types.hpp: TrainArgs; one chain per launch): the point was left in device memory by the launch
   // before this one on the stream, and that launch's record is passed on to the host
   if (GRAD && a.train.enabled && a.train.use_slot >= 0) {
-    const double* tr = a.train.slots[a.train.use_slot].tr;
-    p.perm_n = tr[1];
-    p.temp_n = tr[2];
-    p.rho_n = tr[3];
-    p.init_n = tr[4];
-    p.perm_s = tr[5];
-    p.rho_s = tr[6];
-    p.init_s = tr[10];
-    p.b_n = tr[11];
-    p.d_n = tr[12];
-    p.b_s = tr[14];
-    p.d_s = tr[15];
+    abdi::chain_par_from_tr(p, a.train.slots[a.train.use_slot].tr);
     if (a.train.fwd_rec && b == 0 && wave == ABD_WAVES_PER_BLOCK - 1) train_forward_record(a.train, lane);
   }
   const int seg = b < a.ob_n ? 0 : (b < a.ob_n + a.ob_s ? 1 : 2);

@@ -263,9 +263,9 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   // dense trains: units of 1, 2 or 4 chains (abd_sampler::dtrains)
   s->dtrains = trains_ok && c->dense;
   // as few chains per unit as keep the units within the four hardware queues (a queue runs one kernel at a time): measured at
-  // config 3, evaluations/s seen by NUTS while all chains are at work, units of 1 / 2 / 4 chains -- 4 chains 138 k / 138 k /
-  // 102 k; 8 chains 124 k / 162 k / 161 k; 16 chains - / 149 k / 176 k
-  if (s->dtrains) dense_unit = n <= 4 ? 1 : (n <= 8 ? 2 : 4);
+  // config 3, evaluations/s seen by NUTS while all chains are at work, units of 1 / 2 / 4 chains -- 4 chains 139 k / 138 k /
+  // 102 k; 8 chains 140 k / 176 k / 183 k; 16 chains - / 149 k / 195 k
+  if (s->dtrains) dense_unit = n <= 4 ? 1 : (n < 8 ? 2 : 4);
   s->unit = (c->dense && ((int64_t)c->G * c->N >= 500000 || s->dtrains)) ? dense_unit : std::max(s->threads > 1 ? 1 : 2, std::min(8, (n + 3) / 4));
   s->unit = env_int("ABD_SAMPLER_UNIT", s->unit);
   s->unit = std::max(1, std::min({s->unit, n, (int)ABD_MAX_BATCH}));

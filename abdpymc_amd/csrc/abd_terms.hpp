@@ -161,6 +161,25 @@ ABD_HD void assemble_terms(const ModelSizes& m, const HostTerms& h, const double
   }
 }
 
+// The theta-derived constants of a ChainPar from the backward transforms `tr` (indexed like theta: Transformed).  ONE list of
+// fields for the host (abd_context.hip: chain_par) and for the kernels of a leapfrog train, which take the constants of the
+// point their predecessor left in device memory (abd_dense.hpp: dense_body, abd_obs.hpp): a field added to ChainPar is added
+// here, or the static_assert below stops the build.
+ABD_HD void chain_par_from_tr(ChainPar& p, const double* tr) {
+  p.perm_n = tr[1];
+  p.temp_n = tr[2];
+  p.rho_n = tr[3];
+  p.init_n = tr[4];
+  p.perm_s = tr[5];
+  p.rho_s = tr[6];
+  p.init_s = tr[10];
+  p.b_n = tr[11];
+  p.d_n = tr[12];
+  p.b_s = tr[14];
+  p.d_s = tr[15];
+}
+static_assert(sizeof(ChainPar) == 11 * sizeof(double) + 4 * sizeof(void*), "ChainPar changed: review chain_par_from_tr (11 constants) and chain_par (4 pointers)");
+
 // ---- the same closed forms, one value variable per caller: lane k of a wave computes what belongs to theta[k] ----
 // (abd_dense.hpp: a leapfrog train's launch assembles its own result; a serial pass over the 17 variables costs one lane
 // ~600 dependent fp64 operations, ~2.5 us between two launches of a chain)

@@ -226,6 +226,7 @@ struct EvalArgs {
   // observation-lane kernel: the workgroup of a chain that finishes last sums that chain's partial rows itself
   // (abd_obs.hpp) -- one launch per evaluation instead of two.  fin_count: one zeroed counter per grid row.
   unsigned int* fin_count;
+  unsigned int* fin_count2;  // dense kernel, a grid of more than ABD_TRAIN_ONE_LEVEL workgroups: counters of the two-level count-in, one set per grid row (abd_dense.hpp: two_level_sums)
   double* fin_out;
   double fin_tag;
   int32_t G, N, nt, n_chunks;

@@ -284,5 +284,19 @@ def test_pymc_shaped_step_over_the_device_sweep(test_td):
     for k in range(3):
         p2, _ = solo.astep(p2)
     assert solo.mirror.uploads == 1 and solo.mirror.hits == 2
+    # copies of one step method (what pm.sample hands its chains) must not share a random stream: without a seed each copy
+    # draws its own at its first sweep, or takes the generator PyMC gives the chain's step
+    import copy
+
+    proto = GibbsSweepStep(twin, chain=0)
+    a_step, b_step = copy.copy(proto), copy.copy(proto)
+    assert proto.seed is None
+    a_step.astep(dict(pt))
+    b_step.astep(dict(pt))
+    assert a_step.seed is not None and a_step.seed != b_step.seed and proto.seed is None
+    c_step, d_step = copy.copy(proto), copy.copy(proto)
+    c_step.set_rng(np.random.default_rng(1))
+    d_step.set_rng(np.random.default_rng(1))
+    assert c_step.seed == d_step.seed  # (the same generator state gives the same stream: reproducible runs)
     m.close()
     twin.close()

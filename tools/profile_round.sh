@@ -16,12 +16,19 @@ for cfg in $CFGS; do
     c5) SW="--n-inds 100000 --n-gaps 200 --chains 1 --storage f32 --cpw 1 --blocks 0,256" ;;
     c1) SW="" ;;
   esac
-  echo "== $cfg: bench line" ; python3 bench.py --config $cfg > "$OUT/${cfg}_bench.json" 2> "$OUT/${cfg}_bench.err" || { echo bench failed; tail -5 "$OUT/${cfg}_bench.err"; exit 1; }
+  echo "== $cfg: bench line" ; python3 bench.py --config $cfg --no-other-configs > "$OUT/${cfg}_bench.json" 2> "$OUT/${cfg}_bench.err" || { echo bench failed; tail -5 "$OUT/${cfg}_bench.err"; exit 1; }
   echo "== $cfg: kernel trace of the same command"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace" -- python3 bench.py --config $cfg --no-cpu-baseline > "$OUT/${cfg}_bench_under_rocprof.json" 2> "$OUT/${cfg}_trace.err" || { echo trace failed; tail -5 "$OUT/${cfg}_trace.err"; exit 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace" -- python3 bench.py --config $cfg --no-cpu-baseline --no-other-configs > "$OUT/${cfg}_bench_under_rocprof.json" 2> "$OUT/${cfg}_trace.err" || { echo trace failed; tail -5 "$OUT/${cfg}_trace.err"; exit 1; }
   find "$OUT/${cfg}_trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/${cfg}_kernel_stats.csv" \;
+  if [ $cfg = c3 ]; then
+    echo "== the driver's command: python3 bench.py --gpus 1 --steps 20 --warmup 5 (every single-GPU BASELINE config in one line)"
+    ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/driver_bench.json" ) 2> "$OUT/driver_bench.err" || { echo driver bench failed; tail -5 "$OUT/driver_bench.err"; exit 1; }
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/driver_trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/driver_bench_under_rocprof.json" 2> "$OUT/driver_trace.err" || { echo driver trace failed; exit 1; }
+    find "$OUT/driver_trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/driver_kernel_stats.csv" \;
+    rm -rf "$OUT/driver_trace"
+  fi
   echo "== $cfg: isolated kernel (ABD_PIPES=1)"
-  ABD_PIPES=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace1" -- python3 bench.py --config $cfg --no-cpu-baseline > "$OUT/${cfg}_bench_one_pipe_under_rocprof.json" 2> "$OUT/${cfg}_trace1.err" || { echo trace1 failed; exit 1; }
+  ABD_PIPES=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace1" -- python3 bench.py --config $cfg --no-cpu-baseline --no-sampler > "$OUT/${cfg}_bench_one_pipe_under_rocprof.json" 2> "$OUT/${cfg}_trace1.err" || { echo trace1 failed; exit 1; }
   find "$OUT/${cfg}_trace1" -name "*kernel_stats.csv" -exec cp {} "$OUT/${cfg}_one_pipe_kernel_stats.csv" \;
   [ -z "$SW" ] && { rm -rf "$OUT/${cfg}_trace" "$OUT/${cfg}_trace1"; continue; }  # observation lists: launch-bound, no counter passes
   echo "== $cfg: PMC passes over tools/sweep.py $SW"
@@ -45,10 +52,29 @@ if [ "${GIBBS:-1}" = "1" ]; then
     rm -rf "$OUT/gibbs_pmc"
     ABD_GIBBS_V1=1 python3 tools/probe_gibbs.py 10 $arg > "$OUT/gibbs_${mode}_time_wave_per_proposal_kernel.txt" 2>&1
   done
-  for c in 1 2 4 8 16; do python3 tools/probe_nuts_rate.py c3 $c 300; done > "$OUT/nuts_rate_c3.txt" 2>&1
-  ABD_SAMPLER_TRAINS=0 python3 tools/probe_nuts_rate.py c3 4 300 > "$OUT/nuts_rate_c3_without_trains.txt" 2>&1
+  python3 tools/probe_gibbs_gaps.py 200 256 300 512 > "$OUT/gibbs_gaps.txt" 2>&1
+  ABD_GIBBS_V1=1 python3 tools/probe_gibbs_gaps.py 200 300 >> "$OUT/gibbs_gaps.txt" 2>&1
+  python3 tools/probe_gibbs_scaling.py > "$OUT/gibbs_one_chain_by_cohort_size.txt" 2>&1
+  for c in 1 2 4 8 16; do ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 python3 tools/probe_nuts_rate.py c3 $c 200; done > "$OUT/nuts_rate_c3.txt" 2>&1
+  for u in 1 2 4; do ABD_SAMPLER_UNIT=$u ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 python3 tools/probe_nuts_rate.py c3 8 200; done > "$OUT/nuts_rate_c3_8_chains_by_unit.txt" 2>&1
+  ABD_SAMPLER_TRAINS=0 ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 python3 tools/probe_nuts_rate.py c3 4 200 > "$OUT/nuts_rate_c3_without_trains.txt" 2>&1
+  # the kernel a NUTS chain's leapfrogs run (one chain per train unit): counters in their own pass
+  ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 ABD_PROBE_TUNE=30 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d "$OUT/train_pmc" --output-format csv -- python3 tools/probe_nuts_rate.py c3 4 10 > "$OUT/train_pmc.log" 2>&1
+  python3 tools/pmc_summary.py "$OUT/train_pmc" abd_train > "$OUT/train_kernel_pmc_sq.txt" 2>&1
+  ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 ABD_PROBE_TUNE=30 rocprofv3 --pmc FETCH_SIZE -d "$OUT/train_pmc" --output-format csv -- python3 tools/probe_nuts_rate.py c3 4 10 > "$OUT/train_pmc.log" 2>&1
+  python3 tools/pmc_summary.py "$OUT/train_pmc" abd_train > "$OUT/train_kernel_pmc_fetch_size.txt" 2>&1
+  ABD_PROBE_SAME_STATE=1 ABD_PROBE_THETA_ROW=5 ABD_PROBE_TUNE=60 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -- python3 tools/probe_nuts_rate.py c3 4 60 > "$OUT/train_trace.log" 2>&1
+  find "$OUT/train_trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/nuts_c3_kernel_stats.csv" \;
+  rm -rf "$OUT/train_pmc" "$OUT/train_trace"
+  # abdpymc-infer at BASELINE config 3's size: a cohort directory in the reference's format, thinned recording
+  python3 tools/make_cohort_dir.py /tmp/abd_c3_cohort 10000 200 > "$OUT/cli_c3.txt" 2>&1
+  python3 tools/run_with_rss.py python3 -m abdpymc_amd.cli --ititers_data /tmp/abd_c3_cohort --tune 100 --draws 200 --chains 4 --thin 50 --netcdf /tmp/abd_c3_post >> "$OUT/cli_c3.txt" 2>&1
+  python3 -c "import numpy as np; z = np.load('/tmp/abd_c3_post.npz'); print({k: z[k].shape for k in ('p', 'i', 'ab_n_mu', 'mean_i', 'mean_ab_n_mu', 'mean_ab_s_mu', 'draw_index')})" >> "$OUT/cli_c3.txt" 2>&1
+  rm -rf /tmp/abd_c3_cohort /tmp/abd_c3_post.npz
   python3 tools/probe_sync_latency.py > "$OUT/sync_latency_c3.txt" 2>&1
   for c in 4 16; do python3 tools/probe_nuts_rate.py default $c 300; done > "$OUT/nuts_rate_default_cohort.txt" 2>&1
+  ABD_SAMPLER_UNIT=1 python3 tools/probe_dense_determinism.py 6 4 10000 200 > "$OUT/determinism_c3.txt" 2>&1
+  ABD_SAMPLER_UNIT=2 python3 tools/probe_dense_determinism.py 6 8 10000 200 >> "$OUT/determinism_c3.txt" 2>&1
   python3 tools/bench_sampler.py default --chains 4 --tune 1000 --draws 1000 > "$OUT/sampler_default_cohort.txt" 2>&1
   python3 tools/bench_sampler.py default --chains 4 --tune 1000 --draws 1000 --dense >> "$OUT/sampler_default_cohort.txt" 2>&1
   python3 tools/bench_sampler.py default --chains 16 --tune 1000 --draws 1000 --no-record >> "$OUT/sampler_default_cohort.txt" 2>&1

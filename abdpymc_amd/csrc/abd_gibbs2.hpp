@@ -62,7 +62,7 @@ __host__ __device__ inline size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 
 __host__ __device__ inline int abd_g2_words(int G) { return (G + 63) / 64 > ABD_MAXT ? ABD_MAXT_MAX : ABD_MAXT; }
 // per-wave LDS bytes (12.4 KB at G = 200, fp64: LDS, not registers, decides how many waves a CU holds)
 struct G2Layout {
-  size_t dataS, suf, accw, plist, result, rows, epos, i0pos, ipos, vpos, inl, total;
+  size_t dataS, suf, accw, plist, result, rows, epos, i0pos, ipos, tpos, vpos, inl, total;
 };
 __host__ __device__ inline G2Layout abd_g2_layout(int G, int rbytes) {
   G2Layout L;
@@ -85,6 +85,8 @@ __host__ __device__ inline G2Layout abd_g2_layout(int G, int rbytes) {
   b += abd_g2_pad16((size_t)(G + 1) * 2);            // positions of i0, ascending
   L.ipos = b;
   b += abd_g2_pad16((size_t)(G / 4 + 2) * 2);        // positions of the kept infections I, ascending (at most one in four gaps)
+  L.tpos = b;
+  b += abd_g2_pad16((size_t)(G / 4 + 2) * 2);        // the kept infections of a proposed state the whole wave evaluates (ABD_G2_COMPLEX)
   L.vpos = b;
   b += abd_g2_pad16((size_t)(G + 1) * 2);            // positions of the vaccinations, ascending
   L.inl = b;
@@ -172,22 +174,6 @@ __device__ __forceinline__ int first_bit(const uint64_t (&w)[MT]) {  // position
   return p;
 }
 
-// a wave-uniform row shifted down by g gaps (bit 0 of the result = gap g)
-template <int MT>
-__device__ __forceinline__ void shift_row_down(const uint64_t (&w)[MT], int g, uint64_t (&out)[MT]) {
-  const int q = g >> 6, sh = g & 63;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    uint64_t lo = 0, hi = 0;
-#pragma unroll
-    for (int k = 0; k < MT; ++k) {
-      lo = t + q == k ? w[k] : lo;
-      hi = t + q + 1 == k ? w[k] : hi;
-    }
-    out[t] = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-  }
-}
-
 // both antigens' likelihood term of one gap: -1/2 (q_n / sigma_n)^2 - 1/2 (q_s / sigma_s)^2 (terms that do not depend
 // on the discrete state are left out: they cancel in every difference)
 __device__ __forceinline__ double g2_term(double an, double xn, double yn, double c_n, double d_n, double nh_n, double as, double xs,
@@ -224,39 +210,45 @@ struct G2Par {  // wave-uniform constants of the chain
 
 // Whole-wave evaluation of one state, lanes = gaps of a round: the two responses at this lane's gap of every round
 // (carry into the round x rho^(lane+1) + this round's exposures at or before the lane, power table) and the term there.
-// The rounds start at gap g_off (0: the whole individual; otherwise I and V are the rows shifted down by g_off and
-// cvn / cvs / ci / civ the state at gap g_off - 1: the rest of one lane's walk, taken over by the whole wave).
+// The state comes as sorted position lists in LDS (no packed rows in scalar registers): infections il[k * istride], k in
+// [ki, ni), vaccinations vl[k], k in [kv, nv), all at or after g_off.  The rounds start at gap g_off (0: the whole individual;
+// otherwise cvn / cvs / ci / civ are the state at gap g_off - 1: the rest of one lane's walk, taken over by the whole wave).
+// Within a round the infections are added in ascending order, then the vaccinations -- the order of the packed rows' words.
 template <typename R, int MT>
-__device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint64_t (&I)[MT],
-                                               const uint64_t (&V)[MT], const double2_t* tab_n, const double2_t* tab_s,
+__device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint16_t* il, int istride, int ki, int ni,
+                                               const uint16_t* vl, int kv, int nv, const double2_t* tab_n, const double2_t* tab_s,
                                                double pwn, double pws, const YX<R>* dataN, const YX<R>* dataS,
                                                const double* tab_e2, double (&term_o)[MT], int g_off = 0, double cvn = 0.0,
                                                double cvs = 0.0, bool ci = false, bool civ = false) {
   // cvn / cvs: responses at the end of the previous round (wave-uniform)
-  const uint64_t le = (2ull << lane) - 1ull;  // bits at or before this lane (lane 63: all ones)
   const int n_rounds = (a.G - g_off + 63) >> 6;
+  // the first listed infection / exposure: from there on the permanent responses are switched on (abd.py:306)
+  const int first_i = ki < ni ? __builtin_amdgcn_readfirstlane((int)il[ki * istride]) : ABD_G2_NONE;
+  const int first_v = kv < nv ? __builtin_amdgcn_readfirstlane((int)vl[kv]) : ABD_G2_NONE;
+  const int first_iv = min(first_i, first_v);
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     term_o[t] = 0.0;
     if (t < n_rounds) {
+      const int r0 = g_off + t * 64, r1 = r0 + 64;  // the round's gaps
       double un = pwn * cvn, us = pws * cvs;
-      uint64_t m = I[t];
-      while (m) {  // wave-uniform loop over this word's infections
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        const int idx = min(max(lane - b + 1, 0), a.G);  // 0 = "in the future"
+      while (ki < ni) {  // wave-uniform loop over this round's infections
+        const int pos = __builtin_amdgcn_readfirstlane((int)il[ki * istride]);
+        if (pos >= r1) break;
+        const int idx = min(max(lane - (pos - r0) + 1, 0), a.G);  // 0 = "in the future"
         un += tab_n[idx].x;
         us += tab_s[idx].x;
+        ++ki;
       }
-      m = V[t];
-      while (m) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        us += tab_s[min(max(lane - b + 1, 0), a.G)].x;
+      while (kv < nv) {
+        const int pos = __builtin_amdgcn_readfirstlane((int)vl[kv]);
+        if (pos >= r1) break;
+        us += tab_s[min(max(lane - (pos - r0) + 1, 0), a.G)].x;
+        ++kv;
       }
-      const bool cum_i = ci || (I[t] & le) != 0;
-      const bool cum_iv = civ || ((I[t] | V[t]) & le) != 0;
-      const int g = g_off + t * 64 + lane;
+      const int g = r0 + lane;
+      const bool cum_i = ci || first_i <= g;
+      const bool cum_iv = civ || first_iv <= g;
       const bool valid = g < a.G;
       const int gg = valid ? g : 0;
       const YX<R> on = dataN[gg], os = dataS[gg];
@@ -267,8 +259,6 @@ __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p
       term_o[t] = valid ? term : 0.0;
       cvn = readlane_f64(un, 63);
       cvs = readlane_f64(us, 63);
-      ci |= I[t] != 0;
-      civ |= (I[t] | V[t]) != 0;
     }
   }
 }
@@ -378,6 +368,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   uint16_t* epos = reinterpret_cast<uint16_t*>(wb + L.epos);
   uint16_t* i0pos = reinterpret_cast<uint16_t*>(wb + L.i0pos);
   uint16_t* ipos = reinterpret_cast<uint16_t*>(wb + L.ipos);
+  uint16_t* tpos = reinterpret_cast<uint16_t*>(wb + L.tpos);
   uint16_t* vpos = reinterpret_cast<uint16_t*>(wb + L.vpos);
   uint16_t* inl = reinterpret_cast<uint16_t*>(wb + L.inl) + lane;  // this lane's list: entry k at inl[k * 64]
 
@@ -575,7 +566,9 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       }
       firstI = first_bit<MT>(I);
       double term[MT];
-      g2_eval_rounds<R, MT>(a, p, lane, I, V, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2, term);
+      __builtin_amdgcn_wave_barrier();  // (the lists are in LDS)
+      g2_eval_rounds<R, MT>(a, p, lane, ipos, 1, 0, n_i, vpos, 0, n_v, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS,
+                            tab_e2, term);
       double carry = 0.0;
       int ln = lane;  // (opaque: left to itself the compiler hoists the scan's six "lane + off < 64" masks out of the
       asm volatile("" : "+v"(ln));  // individual loop and keeps them in 12 scalar registers for the whole kernel)
@@ -800,27 +793,12 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         const int Lw = __builtin_ctzll(old_walkers);
         if (STATS) ++st_tail;
         const int g_l = __builtin_amdgcn_readlane(g, Lw);
-        // the walker's infections from its gap on, as a row shifted down to that gap
-        uint64_t Is[MT], Vs[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) Is[t] = 0;
-        {
-          const int k_l = __builtin_amdgcn_readlane(ki, Lw), n_l = __builtin_amdgcn_readlane(n_new, Lw);
-          const uint16_t* lst = inl - lane + Lw;
-          for (int k = k_l; k < n_l; ++k) {
-            const int rel = __builtin_amdgcn_readfirstlane((int)lst[k * 64]) - g_l;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-              if (t == (rel >> 6)) Is[t] |= 1ull << (rel & 63);
-          }
-          uint64_t V[MT];
-          g2_load_row<MT>(row_v, V);
-          shift_row_down<MT>(V, g_l, Vs);
-        }
+        // the walker's infections from its gap on are entries [ki, n_new) of ITS list, the vaccinations vpos[kv ..)
         const bool ci0 = __builtin_amdgcn_readlane((int)cfn_hi, Lw) != 0, civ0 = __builtin_amdgcn_readlane((int)cfs_hi, Lw) != 0;
         double term[MT];
-        g2_eval_rounds<R, MT>(a, p, lane, Is, Vs, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS, tab_e2,
-                              term, g_l, readlane_f64(tn, Lw), readlane_f64(ts, Lw), ci0, civ0);
+        g2_eval_rounds<R, MT>(a, p, lane, inl - lane + Lw, 64, __builtin_amdgcn_readlane(ki, Lw), __builtin_amdgcn_readlane(n_new, Lw), vpos,
+                              __builtin_amdgcn_readlane(kv, Lw), n_v, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN,
+                              dataS, tab_e2, term, g_l, readlane_f64(tn, Lw), readlane_f64(ts, Lw), ci0, civ0);
         double tsum = 0.0;
 #pragma unroll
         for (int t = 0; t < MT; ++t) tsum += term[t];
@@ -854,14 +832,14 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
           // the whole wave evaluates the proposed state: the waning flip (rho_j changes at every gap), or an i_raw flip with
           // more new infections than a lane holds
           const bool wn = d == G ? !wj : wj;
-          uint64_t In[MT], V[MT];
-          g2_load_row<MT>(row_v, V);
           double delta_prior;
+          const uint16_t* il = ipos;  // the proposed state's infections: the current ones (waning flip) ...
+          int nil = n_i;
           if (d == G) {
-            g2_load_row<MT>(row_i, In);
             delta_prior = wn ? theta7 : -theta7;  // Bernoulli(waner | p_waner) abd.py:373
           } else {
-            uint64_t Rn[MT], P[MT], I0n[MT], none[MT];
+            // ... or those of the flipped raw row, constrained from scratch (abd.py:640-667), as a list
+            uint64_t Rn[MT], P[MT], I0n[MT], In[MT], none[MT];
             g2_load_row<MT>(row_r, Rn);
             g2_load_row<MT>(row_p, P);
             bool was_one = false;
@@ -876,9 +854,15 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
             constrain_i0<MT>(Rn, P, a, I0n);
             three_gaps_from<MT>(I0n, none, 0, In);
             delta_prior = was_one ? -theta0 : theta0;
+            nil = 0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) nil = g2_append_positions(In[t], t, lane, tpos, nil, 0);
+            il = tpos;
+            __builtin_amdgcn_wave_barrier();
           }
           double term[MT];
-          g2_eval_rounds<R, MT>(a, p, lane, In, V, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS, tab_e2, term);
+          g2_eval_rounds<R, MT>(a, p, lane, il, 1, 0, nil, vpos, 0, n_v, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS,
+                                tab_e2, term);
           double tsum = 0.0;
 #pragma unroll
           for (int t = 0; t < MT; ++t) tsum += term[t];

@@ -58,14 +58,15 @@
 #endif
 
 #define ABD_G2_MAX_WAVES 12  // waves of a workgroup (= of a CU: one workgroup per CU, three waves per SIMD, <= 168 registers)
-__host__ __device__ inline size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 * 16; }
-__host__ __device__ inline int abd_g2_words(int G) { return (G + 63) / 64 > ABD_MAXT ? ABD_MAXT_MAX : ABD_MAXT; }
+#define ABD_G2_MAX_WAVES_WIDE 8  // ... of the 512-gap kernel: its LDS holds fewer anyway, and two waves per SIMD may use 256 registers
+__host__ __device__ constexpr size_t abd_g2_pad16(size_t b) { return (b + 15) / 16 * 16; }
+__host__ __device__ constexpr int abd_g2_words(int G) { return (G + 63) / 64 > ABD_MAXT ? ABD_MAXT_MAX : ABD_MAXT; }
 // per-wave LDS bytes (12.4 KB at G = 200, fp64: LDS, not registers, decides how many waves a CU holds)
 struct G2Layout {
   size_t dataS, suf, accw, plist, result, rows, epos, i0pos, ipos, tpos, vpos, inl, total;
 };
-__host__ __device__ inline G2Layout abd_g2_layout(int G, int rbytes) {
-  G2Layout L;
+__host__ __device__ constexpr G2Layout abd_g2_layout(int G, int rbytes) {
+  G2Layout L{};
   size_t b = abd_g2_pad16((size_t)G * 2 * rbytes);  // {od, log_dilution} per gap, N ...
   L.dataS = b;
   b += abd_g2_pad16((size_t)G * 2 * rbytes);         // ... then S
@@ -94,16 +95,18 @@ __host__ __device__ inline G2Layout abd_g2_layout(int G, int rbytes) {
   L.total = b;
   return L;
 }
+// (the kernel lays a wave's regions out for the gap CAPACITY of its template, 256 or 512, so that their offsets are immediates)
 __host__ __device__ inline size_t abd_g2_wave_lds(int G, int rbytes) { return abd_g2_layout(G, rbytes).total; }
-// LDS of the tables every wave of the workgroup shares: [2][G+1] power tables + [G+1] ones + 2^(j/1024)
+// LDS of the tables every wave of the workgroup shares: [2][G+1] power tables + [G+1] ones + 2^(j/1024) + the chunk masks
 __host__ __device__ inline size_t abd_g2_shared_lds(int G) {
-  return (size_t)3 * (G + 1) * sizeof(double2_t) + (size_t)ABD_EXP2_TAB * sizeof(double);
+  return (size_t)3 * (G + 1) * sizeof(double2_t) + (size_t)ABD_EXP2_TAB * sizeof(double) + (size_t)3 * ABD_MAXT_MAX * 8;
 }
 // waves per workgroup that fit the CU's 160 KB (0: not even one)
 __host__ __device__ inline int abd_g2_waves(int G, int rbytes) {
   const size_t avail = (size_t)160 * 1024 - abd_g2_shared_lds(G);
   const size_t w = avail / abd_g2_wave_lds(G, rbytes);
-  return (int)(w > ABD_G2_MAX_WAVES ? ABD_G2_MAX_WAVES : w);
+  const size_t cap = abd_g2_words(G) > ABD_MAXT ? ABD_G2_MAX_WAVES_WIDE : ABD_G2_MAX_WAVES;
+  return (int)(w > cap ? cap : w);
 }
 __host__ __device__ inline size_t abd_g2_lds(int G, int rbytes, int n_waves) {
   return abd_g2_shared_lds(G) + (size_t)n_waves * abd_g2_wave_lds(G, rbytes);
@@ -111,23 +114,24 @@ __host__ __device__ inline size_t abd_g2_lds(int G, int rbytes, int n_waves) {
 
 // i0 of constrain_infections before the three-gap pass (abd.py:643-647 one chunk; abd.py:818 + 771 per chunk otherwise).
 // Works on wave-uniform and on per-lane words alike.
+// cmk: the chunk masks, [3][ABD_MAXT_MAX] (EvalArgs::chunk_mask; the sweep kernel keeps a copy in LDS)
 template <int MT>
-__device__ __forceinline__ void constrain_i0(const uint64_t (&raw)[MT], const uint64_t (&pcr)[MT], const EvalArgs& a,
+__device__ __forceinline__ void constrain_i0(const uint64_t (&raw)[MT], const uint64_t (&pcr)[MT], int n_chunks, const uint64_t* cmk,
                                              uint64_t (&i0)[MT]) {
-  if (a.n_chunks <= 1) {
+  if (n_chunks <= 1) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) i0[t] = raw[t] | pcr[t];
   } else {
 #pragma unroll
     for (int t = 0; t < MT; ++t) i0[t] = 0;
-    for (int c = 0; c < a.n_chunks; ++c) {
+    for (int c = 0; c < n_chunks; ++c) {
       bool has_pcr = false;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) has_pcr |= (pcr[t] & a.chunk_mask[c][t]) != 0;
+      for (int t = 0; t < MT; ++t) has_pcr |= (pcr[t] & cmk[c * ABD_MAXT_MAX + t]) != 0;
       bool found = false;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const uint64_t cm = a.chunk_mask[c][t];
+        const uint64_t cm = cmk[c * ABD_MAXT_MAX + t];
         const uint64_t r = raw[t] & cm;
         const uint64_t first = found ? 0ull : (r & (0ull - r));
         found |= r != 0;
@@ -215,13 +219,13 @@ struct G2Par {  // wave-uniform constants of the chain
 // otherwise cvn / cvs / ci / civ are the state at gap g_off - 1: the rest of one lane's walk, taken over by the whole wave).
 // Within a round the infections are added in ascending order, then the vaccinations -- the order of the packed rows' words.
 template <typename R, int MT>
-__device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p, int lane, const uint16_t* il, int istride, int ki, int ni,
+__device__ __forceinline__ void g2_eval_rounds(int G, const G2Par& p, int lane, const uint16_t* il, int istride, int ki, int ni,
                                                const uint16_t* vl, int kv, int nv, const double2_t* tab_n, const double2_t* tab_s,
                                                double pwn, double pws, const YX<R>* dataN, const YX<R>* dataS,
                                                const double* tab_e2, double (&term_o)[MT], int g_off = 0, double cvn = 0.0,
                                                double cvs = 0.0, bool ci = false, bool civ = false) {
   // cvn / cvs: responses at the end of the previous round (wave-uniform)
-  const int n_rounds = (a.G - g_off + 63) >> 6;
+  const int n_rounds = (G - g_off + 63) >> 6;
   // the first listed infection / exposure: from there on the permanent responses are switched on (abd.py:306)
   const int first_i = ki < ni ? __builtin_amdgcn_readfirstlane((int)il[ki * istride]) : ABD_G2_NONE;
   const int first_v = kv < nv ? __builtin_amdgcn_readfirstlane((int)vl[kv]) : ABD_G2_NONE;
@@ -235,7 +239,7 @@ __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p
       while (ki < ni) {  // wave-uniform loop over this round's infections
         const int pos = __builtin_amdgcn_readfirstlane((int)il[ki * istride]);
         if (pos >= r1) break;
-        const int idx = min(max(lane - (pos - r0) + 1, 0), a.G);  // 0 = "in the future"
+        const int idx = min(max(lane - (pos - r0) + 1, 0), G);  // 0 = "in the future"
         un += tab_n[idx].x;
         us += tab_s[idx].x;
         ++ki;
@@ -243,13 +247,13 @@ __device__ __forceinline__ void g2_eval_rounds(const EvalArgs& a, const G2Par& p
       while (kv < nv) {
         const int pos = __builtin_amdgcn_readfirstlane((int)vl[kv]);
         if (pos >= r1) break;
-        us += tab_s[min(max(lane - (pos - r0) + 1, 0), a.G)].x;
+        us += tab_s[min(max(lane - (pos - r0) + 1, 0), G)].x;
         ++kv;
       }
       const int g = r0 + lane;
       const bool cum_i = ci || first_i <= g;
       const bool cum_iv = civ || first_iv <= g;
-      const bool valid = g < a.G;
+      const bool valid = g < G;
       const int gg = valid ? g : 0;
       const YX<R> on = dataN[gg], os = dataS[gg];
       const double an = p.init_n + (cum_i ? p.perm_n : 0.0) + p.temp_n * un;
@@ -341,20 +345,30 @@ __device__ __forceinline__ int g2_append_positions(uint64_t m, int t, int lane, 
 }
 
 // STATS: the development counters of ABD_GIBBS_STATS=1 (seven wave-uniform 64-bit counters)
+// a wave-uniform value the compiler cannot see through (nor hoist what is computed from it out of the loop it is made in)
+__device__ __forceinline__ int g2_opaque_uniform(int x) {
+  asm volatile("" : "+v"(x));
+  return __builtin_amdgcn_readfirstlane(x);
+}
+
 template <typename R, bool STATS, int MT>
-__global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
+__global__ __launch_bounds__(64 * (MT > ABD_MAXT ? ABD_G2_MAX_WAVES_WIDE : ABD_G2_MAX_WAVES), MT > ABD_MAXT ? 2 : 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
-  const int G = a.G, N = a.N, nt = a.nt;
+  const int G0 = a.G, N = a.N, nt0 = a.nt, nch0 = a.n_chunks;
+  const int G = G0;
   const int tstride = G + 1;
   double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   double2_t* tab_ones = tabs + 2 * tstride;
   double* tab_e2 = reinterpret_cast<double*>(tab_ones + tstride);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_threads = (int)blockDim.x;  // 64 x the waves that fit the CU's LDS (abd_g2_waves)
-  const G2Layout L = abd_g2_layout(G, (int)sizeof(R));
-  unsigned char* wb = reinterpret_cast<unsigned char*>(tab_e2 + ABD_EXP2_TAB) + (size_t)wave * L.total;
+  const G2Layout L = abd_g2_layout(G0, (int)sizeof(R));
+  // the chunk masks, [3][ABD_MAXT_MAX], are read from LDS where they are needed: as kernel arguments the compiler loaded all 24
+  // words in front of the individual loop and kept them, spilled, for the whole kernel
+  uint64_t* cmk = reinterpret_cast<uint64_t*>(tab_e2 + ABD_EXP2_TAB);
+  unsigned char* wb = reinterpret_cast<unsigned char*>(cmk + 3 * ABD_MAXT_MAX) + (size_t)wave * L.total;
   YX<R>* dataN = reinterpret_cast<YX<R>*>(wb);
   YX<R>* dataS = reinterpret_cast<YX<R>*>(wb + L.dataS);
   double* suf = reinterpret_cast<double*>(wb + L.suf);
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   uint16_t* ipos = reinterpret_cast<uint16_t*>(wb + L.ipos);
   uint16_t* tpos = reinterpret_cast<uint16_t*>(wb + L.tpos);
   uint16_t* vpos = reinterpret_cast<uint16_t*>(wb + L.vpos);
-  uint16_t* inl = reinterpret_cast<uint16_t*>(wb + L.inl) + lane;  // this lane's list: entry k at inl[k * 64]
+  uint16_t* inl = reinterpret_cast<uint16_t*>(wb + L.inl) + lane0;  // this lane's list: entry k at inl[k * 64]
 
   const int c = blockIdx.y;  // one chain per block row
   const ChainPar& cp = a.ch[c];
@@ -378,6 +392,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   fill_pow_table(tabs + tstride, cp.rho_s, tstride, tid, n_threads);
   fill_ones_table(tab_ones, tstride, tid, n_threads);
   for (int e = tid; e < ABD_EXP2_TAB; e += n_threads) tab_e2[e] = a.exp2_tab[e];
+  if (tid < 3 * ABD_MAXT_MAX) cmk[tid] = a.chunk_mask[tid / ABD_MAXT_MAX][tid % ABD_MAXT_MAX];
   __syncthreads();
 
   // the chain's constants live in VECTOR registers (a spilled scalar costs a v_readlane in the walk)
@@ -397,8 +412,8 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   p.nh_s = to_vgpr(-0.5 * ga.is2_s[c]);
   const double theta0 = ga.theta0[c], theta7 = ga.theta7[c];
   // rho^(lane + 1) = table entry lane + 2 (only used when a previous round exists, i.e. G > 64 >= lane + 1)
-  const double pwn = tabs[min(lane + 2, G)].x, pws_w = tabs[tstride + min(lane + 2, G)].x;
-  const uint32_t k0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1 = ga.seed_hi;
+  const double pwn = tabs[min(lane0 + 2, G)].x, pws_w = tabs[tstride + min(lane0 + 2, G)].x;
+  const uint32_t k0_0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1_0 = ga.seed_hi;
   const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(cp.rw);
   int8_t* waner = const_cast<int8_t*>(cp.waner);
@@ -421,6 +436,15 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
   unsigned long long st_iter = 0, st_refill = 0, st_steps = 0, st_lane_steps = 0, st_tail = 0, st_commit = 0, st_inds = 0;
 
   for (;;) {
+    // (the lane index of this iteration is opaque to the compiler: left to itself it hoists every lane predicate of the loop --
+    // the 36 stages of the sort alone have two dozen, "(lane & J) == 0" -- out of it and keeps them as 64-bit masks for the
+    // whole kernel: 90 of the 287 scalar registers it then had to spill, reloaded at every use)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    // (likewise the word and chunk counts: their comparisons with 0 .. MT - 1 were kept as nineteen 64-bit select masks)
+    // and the twenty round keys of the Philox stream, which only the set-up of an individual needs)
+    const int nt = g2_opaque_uniform(nt0), nch = g2_opaque_uniform(nch0), G = g2_opaque_uniform(G0);
+    const uint32_t k0 = (uint32_t)g2_opaque_uniform((int)k0_0), k1 = (uint32_t)g2_opaque_uniform((int)k1_0);
     // ---- next individual of this chain: one queue per chain, one individual per pop, so that the waves stay busy to the
     // end (guided chunks of up to 8 were measured: the pops themselves got cheaper -- a sweep that proposes nothing 0.54 ->
     // 0.28 ms -- but the coarser hand-out cost more at the end of a real sweep: 0.91 -> 0.95 ms converged, 2.26 -> 2.45 ms random)
@@ -519,7 +543,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         g2_load_row<MT>(row_r, Rw);
         g2_load_row<MT>(row_p, P);
         g2_load_row<MT>(row_v, V);
-        constrain_i0<MT>(Rw, P, a, I0);
+        constrain_i0<MT>(Rw, P, nch, cmk, I0);
         uint64_t none[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) none[t] = 0;
@@ -532,18 +556,19 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
           n_e = g2_append_positions(I[t], t, lane, epos, n_e, 0);
           n_e = g2_append_positions(V[t], t, lane, epos, n_e, 0x8000u);
         }
-        if (a.n_chunks > 1) {
+        if (nch > 1) {
           chunk_pcr = 0;
 #pragma unroll
           for (int cc = 0; cc < 3; ++cc) {
             int f1 = ABD_G2_NONE, f2 = ABD_G2_NONE;
-            if (cc < a.n_chunks) {
+            if (cc < nch) {
               bool has = false;
               uint64_t r[MT];
 #pragma unroll
               for (int t = 0; t < MT; ++t) {
-                has |= (P[t] & a.chunk_mask[cc][t]) != 0;
-                r[t] = Rw[t] & a.chunk_mask[cc][t];
+                const uint64_t cm = cmk[cc * ABD_MAXT_MAX + t];
+                has |= (P[t] & cm) != 0;
+                r[t] = Rw[t] & cm;
               }
               if (has) chunk_pcr |= 1 << cc;
               f1 = first_bit<MT>(r);
@@ -567,7 +592,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
       firstI = first_bit<MT>(I);
       double term[MT];
       __builtin_amdgcn_wave_barrier();  // (the lists are in LDS)
-      g2_eval_rounds<R, MT>(a, p, lane, ipos, 1, 0, n_i, vpos, 0, n_v, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS,
+      g2_eval_rounds<R, MT>(G, p, lane, ipos, 1, 0, n_i, vpos, 0, n_v, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN, dataS,
                             tab_e2, term);
       double carry = 0.0;
       int ln = lane;  // (opaque: left to itself the compiler hoists the scan's six "lane + off < 64" masks out of the
@@ -631,7 +656,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
             const bool was_one = ((row_r[d >> 6] >> (d & 63)) & 1ull) != 0;
             const double delta0 = was_one ? -theta0 : theta0;  // Bernoulli(i_raw | p) on the RAW matrix (abd.py:427)
             int a_rm = ABD_G2_NONE, b_add = ABD_G2_NONE;
-            if (a.n_chunks <= 1) {
+            if (nch <= 1) {
               const bool pcr_bit = a.pw != nullptr && ((row_p[d >> 6] >> (d & 63)) & 1ull) != 0;
               if (!pcr_bit) {  // where(i_raw + pcrpos > 0, 1, 0): a PCR+ gap is an infection either way
                 if (was_one) a_rm = d;
@@ -796,7 +821,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
         // the walker's infections from its gap on are entries [ki, n_new) of ITS list, the vaccinations vpos[kv ..)
         const bool ci0 = __builtin_amdgcn_readlane((int)cfn_hi, Lw) != 0, civ0 = __builtin_amdgcn_readlane((int)cfs_hi, Lw) != 0;
         double term[MT];
-        g2_eval_rounds<R, MT>(a, p, lane, inl - lane + Lw, 64, __builtin_amdgcn_readlane(ki, Lw), __builtin_amdgcn_readlane(n_new, Lw), vpos,
+        g2_eval_rounds<R, MT>(G, p, lane, inl - lane0 + Lw, 64, __builtin_amdgcn_readlane(ki, Lw), __builtin_amdgcn_readlane(n_new, Lw), vpos,
                               __builtin_amdgcn_readlane(kv, Lw), n_v, tabs, wj ? tabs + tstride : tab_ones, pwn, wj ? pws_w : 1.0, dataN,
                               dataS, tab_e2, term, g_l, readlane_f64(tn, Lw), readlane_f64(ts, Lw), ci0, civ0);
         double tsum = 0.0;
@@ -851,7 +876,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
                 Rn[t] ^= 1ull << (d & 63);
               }
             }
-            constrain_i0<MT>(Rn, P, a, I0n);
+            constrain_i0<MT>(Rn, P, nch, cmk, I0n);
             three_gaps_from<MT>(I0n, none, 0, In);
             delta_prior = was_one ? -theta0 : theta0;
             nil = 0;
@@ -861,7 +886,7 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
             __builtin_amdgcn_wave_barrier();
           }
           double term[MT];
-          g2_eval_rounds<R, MT>(a, p, lane, il, 1, 0, nil, vpos, 0, n_v, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS,
+          g2_eval_rounds<R, MT>(G, p, lane, il, 1, 0, nil, vpos, 0, n_v, tabs, wn ? tabs + tstride : tab_ones, pwn, wn ? pws_w : 1.0, dataN, dataS,
                                 tab_e2, term);
           double tsum = 0.0;
 #pragma unroll
@@ -904,16 +929,16 @@ __global__ __launch_bounds__(64 * ABD_G2_MAX_WAVES, 3) void abd_gibbs_dense_kern
     d_m1 += (pc1 >> 16) - (pc0 >> 16);
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0 && (d_n1 | d_m1)) {
+  if (lane0 == 0 && (d_n1 | d_m1)) {
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(const_cast<long long*>(cp.cnt));
     atomicAdd(cnt + 0, (unsigned long long)(long long)d_n1);  // two's complement: a negative change wraps to the right sum
     atomicAdd(cnt + 1, (unsigned long long)(long long)d_m1);
   }
-  if (lane == 0 && (n_acc | n_prop_total)) {
+  if (lane0 == 0 && (n_acc | n_prop_total)) {
     atomicAdd(ga.counts + 2 * c + 0, (unsigned long long)n_acc);
     atomicAdd(ga.counts + 2 * c + 1, (unsigned long long)n_prop_total);
   }
-  if (STATS && lane == 0 && ga.stats) {
+  if (STATS && lane0 == 0 && ga.stats) {
     atomicAdd(ga.stats + 0, st_inds);
     atomicAdd(ga.stats + 1, st_iter);
     atomicAdd(ga.stats + 2, st_refill);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise `hipcc -Rpass-analysis=kernel-resource-usage` output (one line per kernel)."""
+"""Summarise `hipcc -Rpass-analysis=kernel-resource-usage` output (one line per kernel).
+usage: resource_usage.py build/libabd_hip.so.log  (written by __graft_entry__.build_hip whenever it links the library)"""
 import re
 import sys
 
@@ -19,5 +20,7 @@ for b in re.split(r"remark: Function Name: ", txt)[1:]:
         f(r"ScratchSize \[bytes/lane\]"),
         f(r"Occupancy \[waves/SIMD\]"),
         f(r"LDS Size \[bytes/block\]"),
+        f("SGPRs Spill"),
+        f("VGPRs Spill"),
     ]
-    print("{:52s} sgpr {:>4} vgpr {:>4} agpr {:>3} scratch {:>5} occ {:>2} lds {}".format(*row))
+    print("{:52s} sgpr {:>4} vgpr {:>4} agpr {:>3} scratch {:>5} occ {:>2} lds {} spills sgpr {:>3} vgpr {:>3}".format(*row))

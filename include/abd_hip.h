@@ -165,12 +165,20 @@ int abd_deterministics(abd_ctx* ctx, int32_t chain, const double* theta, int8_t*
  * re-evaluation are queued behind each other on its stream, and the host polls completion tags -- no unit waits
  * for another one's trees (as PyMC's one process per chain does not), and their launches overlap on the device.
  * What a unit computes depends only on the unit (fixed launch shape), never on the other units or on timing.
- * Units of ONE chain run leapfrog trains (dense cohorts and observation lists alike; diagonal metric): inside one half
- * of a tree doubling the launch that evaluates a point also assembles logp and gradient, finishes the leapfrog and leaves
- * the next point in device memory for the launch the host has already queued behind it, so a chain's leapfrogs follow
- * each other at the device's pace, not at the host's round trip.  A train run is exactly repeatable and equals the
- * host-driven one (ABD_SAMPLER_TRAINS=0) to rounding, not bit for bit: the closed forms of the transforms are the
- * device's exp / log1p there.
+ * Leapfrog trains (diagonal metric; ABD_SAMPLER_TRAINS): the launch that evaluates a point also assembles logp and gradient,
+ * finishes the leapfrog and leaves the next point in device memory for the launch the host has already queued behind it,
+ * so a chain's leapfrogs follow each other at the device's pace, not at the host's round trip.
+ *   - Dense cohorts (abd_train.hpp): every chain has a small state machine in device memory -- the two ends of its tree, the
+ *     doubling directions of the transition (drawn by the host before the tree starts), the leaves still to go.  A launch takes
+ *     the 1, 2 or 4 chains of its unit one leapfrog further each, whatever stage each of them is in, and goes on ACROSS the
+ *     halves of a doubling and across doublings; the host reads the launches' records from a ring in mapped memory, runs the
+ *     tree logic (U-turn tests, multinomial choice) behind the device and tells the state machine when a transition is over
+ *     (launches queued beyond that point find the chain idle and skip it).  The chain's sweep runs on a side stream of its
+ *     own while the other chains of the unit go on.  Units: one chain up to 4 chains, two up to 7, four beyond.
+ *   - Observation lists: units of one chain; a train ends with the half of the doubling it serves.
+ * A train run is exactly repeatable, does not depend on the other chains or on timing, and equals the host-driven run
+ * (ABD_SAMPLER_TRAINS=0) to rounding, not bit for bit: the closed forms of the transforms are the device's exp / log1p
+ * there.
  * Cohorts kept as observation lists are bound by the host's two kernel launches per evaluation, so their units are
  * driven by T host threads inside abd_sampler_run (T a power of two <= 8, 4 by default; thread t the units u with
  * u mod T == t: what a thread touches is private to its units); dense cohorts are bound by the device and use the calling

@@ -319,11 +319,14 @@ int abd_n_pipes(abd_ctx* ctx);
  *   ABD_GIBBS_V1         0                   1 = dense cohorts sweep with the wave-per-proposal kernel (cross-check)
  *   ABD_DENSE_OWN_SUM    1                   0 = a sampler unit's launch is summed by a second launch (same bits; no leapfrog trains then)
  *   ABD_SAMPLER_THREADS  1 dense / 4 lists   host threads that drive the native sampler's units (<= 8 are used)
- *   ABD_SAMPLER_UNIT     by cohort           chains per independent unit of the native sampler
+ *   ABD_SAMPLER_UNIT     by cohort           chains per independent unit of the native sampler (dense: 1 up to 4 chains, 2 up to 7,
+ *                                            4 beyond; 1, 2 or 4)
  *   ABD_SAMPLER_TRAINS   1                   0 = no leapfrog trains: the host sees every leapfrog before the next is queued
  *   ABD_SAMPLER_PROFILE  0                   1 = abd_sampler_run reports on stderr where the host thread's time went
  *   ABD_GIBBS_STATS      0                   1 = abd_gibbs_sweep reports the dense sweep's scheduler counters on stderr
- * (The Python layer adds ABD_HIP_LIB, the path of this library, and bench.py ABD_DIST_BACKEND.) */
+ * (The Python layer adds ABD_HIP_LIB, the path of this library, and ABD_RECORD_BUDGET_GB, the host memory a process may spend
+ * on per-draw (G, N) records; bench.py adds ABD_DIST_BACKEND.  The HIP runtime's HIP_FORCE_DEV_KERNARG must stay at its
+ * default of 1: kernel arguments in host memory cost 3-5 us per launch.) */
 
 #ifdef __cplusplus
 }

@@ -608,17 +608,20 @@ def test_observation_list_trains_follow_the_host_driven_chain(test_td, monkeypat
     np.testing.assert_allclose(s_a["lp"][:, :3], s_host["lp"][:, :3], rtol=1e-9)
 
 
-def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch):
-    """Leapfrog trains (dense cohort, one chain per unit; on by default): inside a half of a tree doubling the launch that
-    evaluates a point assembles logp and gradient on the device, finishes the leapfrog and leaves the next point for the
-    launch queued behind it.  Same transition, same random stream as the host-driven chain; the device's closed forms
-    (exp, log1p) round differently from the host's, so the chains agree to rounding, not bit for bit: the first
-    transitions build the same trees and end within 1e-7 of each other; and a train run repeats itself exactly, whatever
-    the look-ahead did (it depends on timing only)."""
+@pytest.mark.parametrize("unit,C", [("1", 3), ("2", 4), ("4", 4)])
+def test_leapfrog_trains_follow_the_host_driven_chain(monkeypatch, unit, C):
+    """Leapfrog trains (dense cohort; units of one, two and four chains; on by default): the launch that evaluates a point
+    assembles logp and gradient on the device, finishes the leapfrog -- across the halves and doublings of the tree, from the
+    chain's state machine in device memory -- and leaves the next point for the launch queued behind it; the host runs the
+    tree logic on the records.  Same transition, same random stream as the host-driven chain (same unit, so the same range
+    split); the device's closed forms (exp, log1p) round differently from the host's, so the chains agree to rounding, not
+    bit for bit: the first transitions build the same trees and end within 1e-7 of each other; and a train run repeats
+    itself exactly, whatever the look-ahead did (it depends on timing only)."""
     from abdpymc_amd._native import Context
 
-    N, G, C = 700, 70, 3
+    N, G = 700, 70
     sc = synthetic.make_cohort(N, G, seed=9)
+    monkeypatch.setenv("ABD_SAMPLER_UNIT", unit)
 
     def run(trains):
         monkeypatch.setenv("ABD_SAMPLER_TRAINS", trains)

@@ -211,7 +211,7 @@ ChainPar chain_par(const abd_ctx* c, int chain, const Transformed& tr);
 ChainPar chain_par(const abd_ctx* c, int chain, const double* t);
 void base_args(const abd_ctx* c, EvalArgs& a);
 #ifdef ABD_STAMPS
-unsigned long long* stamps_buffer();  // diagnostic build: in-kernel s_memrealtime stamps (tools/probe_stamps.py, probe_train_stamps.py)
+unsigned long long* stamps_buffer();  // diagnostic build: in-kernel s_memrealtime stamps (tools/probe_stamps.py)
 #endif
 int probe_stream_queues(abd_ctx* c);
 inline int unit_pipe(const abd_ctx* c, int u) { return c->pipe_order[u % c->n_streams]; }

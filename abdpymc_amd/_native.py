@@ -476,7 +476,8 @@ class Context:
     def sampler(self, chains, theta0, tune: int, seed: int = 0, target_accept: float = 0.8, max_treedepth: int = 10,
                 gibbs: bool = True, accumulate: bool = False, chain_offset: int = 0,
                 dense_metric: bool = False) -> "NativeSampler":
-        """The compound step [NUTS; Gibbs sweep] for several chains in lock step, driven inside the library."""
+        """The compound step [NUTS; Gibbs sweep] for several chains, driven inside the library: the chains advance as
+        independent units on their own HIP streams (abd_hip.h: abd_sampler_create)."""
         return NativeSampler(self, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate, chain_offset,
                              dense_metric)
 
@@ -553,7 +554,8 @@ class DiscreteMirror:
 
 
 class NativeSampler:
-    """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922), one launch per lock-step leapfrog."""
+    """``abd_sampler_*``: what ``pm.sample`` runs for this model (abd.py:921-922): independent chains, one evaluation launch
+    per leapfrog of a unit of 1-4 chains, leapfrog trains (abd_hip.h)."""
 
     def __init__(self, ctx: Context, chains, theta0, tune, seed, target_accept, max_treedepth, gibbs, accumulate,
                  chain_offset=0, dense_metric=False):

@@ -185,16 +185,22 @@ __device__ __forceinline__ double sparse_terms(const EvalArgs& a, const ChainPar
   return acc;
 }
 
+// a wave-uniform value the compiler cannot see through (nor hoist what is computed from it out of the loop it is made in)
+__device__ __forceinline__ int gibbs_opaque_uniform(int x) {
+  asm volatile("" : "+v"(x));
+  return __builtin_amdgcn_readfirstlane(x);
+}
+
 template <typename R, bool DENSE, int MT>
 __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga) {
   // LDS: [2][G+1] power tables of the block's chain, [G+1] ones, then abd_gibbs_wave_lds(G) bytes per wave
   extern __shared__ __align__(16) unsigned char smem[];
   const EvalArgs& a = ga.e;
-  const int G = a.G, N = a.N, nt = a.nt;
+  const int G = a.G, N = a.N, nt0 = a.nt;
   const int tstride = G + 1;
   double2_t* tabs = reinterpret_cast<double2_t*>(smem);
   double2_t* tab_ones = tabs + 2 * tstride;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t nd = (size_t)G + 1;
   unsigned char* wbase = reinterpret_cast<unsigned char*>(tab_ones + tstride) + (size_t)wave * abd_gibbs_wave_lds(G);
@@ -211,8 +217,8 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
   __syncthreads();
   const double theta0 = ga.theta0[c], theta7 = ga.theta7[c], is2_n = ga.is2_n[c], is2_s = ga.is2_s[c];
   // rho^(lane + 1) = table entry lane + 2 (only used when a previous round exists, i.e. G > 64 >= lane + 1)
-  const double pwn = tabs[min(lane + 2, G)].x, pws = tabs[tstride + min(lane + 2, G)].x;
-  const uint32_t k0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1 = ga.seed_hi;
+  const double pwn = tabs[min(lane0 + 2, G)].x, pws = tabs[tstride + min(lane0 + 2, G)].x;
+  const uint32_t k0_0 = ga.seed_lo ^ (ga.sweep * 0x9E3779B9u), k1_0 = ga.seed_hi;
   const uint32_t cs = ga.stream[c];
   uint64_t* rw = const_cast<uint64_t*>(p.rw);
   int8_t* waner = const_cast<int8_t*>(p.waner);
@@ -223,6 +229,12 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
 
   const int waves_total = gridDim.x * ABD_WAVES_PER_BLOCK;
   for (int j = blockIdx.x * ABD_WAVES_PER_BLOCK + wave; j < N; j += waves_total) {
+    // (wave-uniform, loop-invariant values that the compiler would otherwise derive masks and key schedules from in front of
+    // the loop and keep, spilled, for the whole kernel are re-made opaque per individual: abd_gibbs2.hpp has the account)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int nt = gibbs_opaque_uniform(nt0);
+    const uint32_t k0 = (uint32_t)gibbs_opaque_uniform((int)k0_0), k1 = (uint32_t)gibbs_opaque_uniform((int)k1_0);
     // ---- this individual's discrete state and data ----
     uint64_t V[MT], P[MT], Rw[MT], I[MT];
     YX<R> dn[MT], ds[MT];
@@ -376,11 +388,11 @@ __global__ __launch_bounds__(ABD_BLOCK) void abd_gibbs_kernel(const GibbsArgs ga
     d_n1 += (pc1 & 0xFFFF) - (pc0 & 0xFFFF);
     d_m1 += (pc1 >> 16) - (pc0 >> 16);
   }
-  if (lane == 0 && (n_acc | n_prop)) {
+  if (lane0 == 0 && (n_acc | n_prop)) {
     atomicAdd(ga.counts + 2 * c + 0, n_acc);
     atomicAdd(ga.counts + 2 * c + 1, n_prop);
   }
-  if (lane == 0 && (d_n1 | d_m1)) {
+  if (lane0 == 0 && (d_n1 | d_m1)) {
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(const_cast<long long*>(p.cnt));
     atomicAdd(cnt + 0, (unsigned long long)d_n1);  // two's complement: a negative change wraps to the right sum
     atomicAdd(cnt + 1, (unsigned long long)d_m1);

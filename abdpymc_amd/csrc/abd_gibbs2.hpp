@@ -345,12 +345,6 @@ __device__ __forceinline__ int g2_append_positions(uint64_t m, int t, int lane, 
 }
 
 // STATS: the development counters of ABD_GIBBS_STATS=1 (seven wave-uniform 64-bit counters)
-// a wave-uniform value the compiler cannot see through (nor hoist what is computed from it out of the loop it is made in)
-__device__ __forceinline__ int g2_opaque_uniform(int x) {
-  asm volatile("" : "+v"(x));
-  return __builtin_amdgcn_readfirstlane(x);
-}
-
 template <typename R, bool STATS, int MT>
 __global__ __launch_bounds__(64 * (MT > ABD_MAXT ? ABD_G2_MAX_WAVES_WIDE : ABD_G2_MAX_WAVES), MT > ABD_MAXT ? 2 : 3) void abd_gibbs_dense_kernel(const GibbsArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -443,8 +437,8 @@ __global__ __launch_bounds__(64 * (MT > ABD_MAXT ? ABD_G2_MAX_WAVES_WIDE : ABD_G
     asm volatile("" : "+v"(lane));
     // (likewise the word and chunk counts: their comparisons with 0 .. MT - 1 were kept as nineteen 64-bit select masks)
     // and the twenty round keys of the Philox stream, which only the set-up of an individual needs)
-    const int nt = g2_opaque_uniform(nt0), nch = g2_opaque_uniform(nch0), G = g2_opaque_uniform(G0);
-    const uint32_t k0 = (uint32_t)g2_opaque_uniform((int)k0_0), k1 = (uint32_t)g2_opaque_uniform((int)k1_0);
+    const int nt = gibbs_opaque_uniform(nt0), nch = gibbs_opaque_uniform(nch0), G = gibbs_opaque_uniform(G0);
+    const uint32_t k0 = (uint32_t)gibbs_opaque_uniform((int)k0_0), k1 = (uint32_t)gibbs_opaque_uniform((int)k1_0);
     // ---- next individual of this chain: one queue per chain, one individual per pop, so that the waves stay busy to the
     // end (guided chunks of up to 8 were measured: the pops themselves got cheaper -- a sweep that proposes nothing 0.54 ->
     // 0.28 ms -- but the coarser hand-out cost more at the end of a real sweep: 0.91 -> 0.95 ms converged, 2.26 -> 2.45 ms random)

@@ -33,6 +33,7 @@ def harness(tmp_path_factory):
         assert rc == 0
         return q, st
 
+    run.lib_path = str(out)
     return run
 
 
@@ -106,3 +107,27 @@ def test_dense_metric_shortens_trees_on_a_correlated_normal(harness):
     depth_dense, depth_diag = sd_stats[..., 1].mean(), s1_stats[..., 1].mean()
     assert depth_dense < 3.6 and depth_diag > depth_dense + 1.5, (depth_dense, depth_diag)
     assert 0.7 < sd_stats[..., 3].mean() < 0.95
+
+
+def test_the_leapfrog_train_protocol_gives_the_classic_draws(harness, tmp_path):
+    """The protocol between the host's tree logic and the device's per-chain state machine (abd_train.hpp; restated on the CPU in
+    the harness): doubling directions drawn when the transition begins, the device taking leapfrog after leapfrog across halves
+    and doublings, the host feeding on the records behind it and ignoring what the device took beyond the end of a tree.  Bit for
+    bit the draws of the classic request / feed loop; with an evaluation of the start point first (the compound step's
+    transition after a sweep) the same again."""
+    lib = C.CDLL(harness.lib_path)
+    dp = C.POINTER(C.c_double)
+    lib.nuts_harness_run_trains.argtypes = [dp, dp, C.c_longlong, C.c_longlong, C.c_ulonglong, C.c_int, C.c_int, C.c_int, dp, dp]
+    lib.nuts_harness_run_trains.restype = C.c_int
+    mean, sd = _target()
+    tune, draws, chains = 300, 200, 3
+    q_ref, st_ref = harness(mean, sd, tune, draws, 7, chains)
+    for eval_first, run_on in ((0, 0), (0, 3), (1, 0), (1, 5)):
+        q = np.empty((chains, draws, 17))
+        st = np.empty((chains, draws, 6))
+        rc = lib.nuts_harness_run_trains(mean.ctypes.data_as(dp), sd.ctypes.data_as(dp), tune, draws, 7, chains, eval_first, run_on,
+                                         q.ctypes.data_as(dp), st.ctypes.data_as(dp))
+        assert rc == 0, (rc, eval_first, run_on)
+        np.testing.assert_array_equal(q, q_ref, err_msg=f"eval_first={eval_first} run_on={run_on}")
+        np.testing.assert_array_equal(st, st_ref)
+    assert st_ref[..., 1].max() >= 3  # trees with several doublings, i.e. halves the device entered by itself

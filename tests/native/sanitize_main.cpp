@@ -1,5 +1,6 @@
 // AddressSanitizer / UBSan driver for the HIP-free host code (CPU only; the GPU side is never sanitised):
-//   * the NUTS state machine of the native sampler (abdpymc_amd/csrc/abd_nuts.hpp) through tests/native/nuts_harness.cpp
+//   * the NUTS state machine of the native sampler (abdpymc_amd/csrc/abd_nuts.hpp) through tests/native/nuts_harness.cpp,
+//     classic loop and leapfrog-train protocol
 //   * the plain-C restatement oracle/abd_oracle.c: logp + gradient (dense and ragged observation lists, 0-2 splits,
 //     ignore_pcrpos) and the Gibbs sweep
 // Built and run by tests/test_sanitizers.py with -fsanitize=address,undefined -fno-sanitize-recover=all.
@@ -11,6 +12,8 @@
 
 extern "C" int nuts_harness_run(const double* mean, const double* sd, const double* prec, long long tune, long long draws,
                                 unsigned long long seed, int n_chains, int dense, double* out_q, double* out_stats);
+extern "C" int nuts_harness_run_trains(const double* mean, const double* sd, long long tune, long long draws, unsigned long long seed,
+                                       int n_chains, int eval_first, int run_on, double* out_q, double* out_stats);
 extern "C" int abd_oracle_logp_dlogp(int G, int N, int n_splits, const int* splits, const int8_t* vacs, const int8_t* pcrpos,
                                      int64_t K_s, const int32_t* s_gap, const int32_t* s_ind, const double* s_x,
                                      const double* s_y, int64_t K_n, const int32_t* n_gap, const int32_t* n_ind,
@@ -108,6 +111,14 @@ int main() {
     int rc = nuts_harness_run(mean.data(), sd.data(), dense ? prec.data() : nullptr, tune, draws, 7ull, chains, dense, q.data(), st.data());
     REQUIRE(rc == 0);
     for (double v : q) REQUIRE(std::isfinite(v));
+    if (!dense) {  // the leapfrog-train protocol (device state machine restated on the CPU): the same draws
+      std::vector<double> q2(q.size()), st2(st.size());
+      for (int eval_first = 0; eval_first < 2; ++eval_first) {
+        rc = nuts_harness_run_trains(mean.data(), sd.data(), tune, draws, 7ull, chains, eval_first, 4, q2.data(), st2.data());
+        REQUIRE(rc == 0);
+        REQUIRE(q2 == q);
+      }
+    }
   }
   // ---- oracle: shapes the reference's tests and BASELINE configs use, small ----
   const int s1[1] = {9}, s2[2] = {7, 15}, s0[1] = {0}, sG[1] = {20};

@@ -282,7 +282,14 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   if (s->dtrains) {
     // the unit's launch shape: the chip's workgroup slots (4 per CU) divided among the units that are in flight together
     const int n_units = (n + s->unit - 1) / s->unit;
-    const int per_cu = std::max(1, std::min(c->dbpc, c->dbpc / std::min(n_units, 4)));
+    int per_cu = std::max(1, std::min(c->dbpc, c->dbpc / std::min(n_units, 4)));
+    // a unit that has the chip to itself: four workgroups per CU only where their ranges are long enough to pay for four times
+    // the set-up (config 5: 77 gap rows per range); otherwise two (config 3, one chain: 43.6 k / 51.7 k / 47.7 k evaluations/s with
+    // 1 / 2 / 4 per CU; profiles/r04/b_train_grid.txt, b_gap_loop_two_gaps_interleaved_ab.txt)
+    if (n_units == 1) {
+      const int64_t rows = (int64_t)c->n_lg * c->G, nsub = ABD_WAVES_PER_BLOCK / std::max(1, s->unit);
+      while (per_cu > 2 && rows / ((int64_t)c->n_cu * per_cu * nsub) < 32) per_cu /= 2;
+    }
     s->dtrain_blocks = dense_blocks(c, s->unit, 0, 1);                      // (the cap that keeps ranges >= kMinRows rows)
     s->dtrain_blocks = std::min(s->dtrain_blocks, c->n_cu * per_cu);
     if (const int tb = tune_int("ABD_TRAIN_BLOCKS_PER_CU", 0)) s->dtrain_blocks = std::max(1, std::min({c->n_cu * tb, c->blocks_max, dense_blocks(c, s->unit, 0, 1)}));

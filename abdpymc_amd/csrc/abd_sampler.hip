@@ -286,6 +286,10 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
     // a unit that has the chip to itself: four workgroups per CU only where their ranges are long enough to pay for four times
     // the set-up (config 5: 77 gap rows per range); otherwise two (config 3, one chain: 43.6 k / 51.7 k / 47.7 k evaluations/s with
     // 1 / 2 / 4 per CU; profiles/r04/b_train_grid.txt, b_gap_loop_two_gaps_interleaved_ab.txt)
+    // units of four chains: one range per workgroup and chain, so one workgroup per CU leaves a launch with 255 long ranges; two
+    // per CU are faster even with four units in flight (16 chains at config 3: 161.7 k -> 171.9 k evaluations/s while all chains are
+    // at work, 124.6 k -> 135.8 k over the call)
+    if (s->unit == 4) per_cu = std::max(per_cu, 2);
     if (n_units == 1) {
       const int64_t rows = (int64_t)c->n_lg * c->G, nsub = ABD_WAVES_PER_BLOCK / std::max(1, s->unit);
       while (per_cu > 2 && rows / ((int64_t)c->n_cu * per_cu * nsub) < 32) per_cu /= 2;

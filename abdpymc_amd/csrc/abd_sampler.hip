@@ -280,19 +280,17 @@ int abd_sampler_create(abd_ctx* c, int32_t n, const int32_t* chains, const doubl
   if (!rc && (n + s->unit - 1) / s->unit > 1 && tune_int("ABD_PROBE_QUEUES", 1) != 0) rc = probe_stream_queues(c);
   s->trains = trains_ok && !c->dense && s->unit == 1;
   if (s->dtrains) {
-    // the unit's launch shape: the chip's workgroup slots (4 per CU) divided among the units that are in flight together
+    // the unit's launch shape: two workgroups per CU, however many units there are (config 3, evaluations/s seen by NUTS over
+    // the call with 1 / 2 per CU: 3 chains 78 k / 78 k but 94 k / 106 k while all are at work, 4 chains 128 k / 129 k and the compound
+    // iteration 966 / 1 027 per s, 5 chains 85 k / 120 k, 7 chains 106 k / 123 k, 16 chains as units of four 125 k / 136 k; 3 or 4
+    // per CU are slower again: profiles/r04/b_train_grid_*.txt): chains finish their trees and iterations at different times, and
+    // a unit that is alone for a while gets through its launches faster on the larger grid.  A unit that is alone for the whole run
+    // takes four per CU where its ranges are long enough to pay for the set-up (config 5: 77 gap rows per range)
     const int n_units = (n + s->unit - 1) / s->unit;
-    int per_cu = std::max(1, std::min(c->dbpc, c->dbpc / std::min(n_units, 4)));
-    // a unit that has the chip to itself: four workgroups per CU only where their ranges are long enough to pay for four times
-    // the set-up (config 5: 77 gap rows per range); otherwise two (config 3, one chain: 43.6 k / 51.7 k / 47.7 k evaluations/s with
-    // 1 / 2 / 4 per CU; profiles/r04/b_train_grid.txt, b_gap_loop_two_gaps_interleaved_ab.txt)
-    // units of four chains: one range per workgroup and chain, so one workgroup per CU leaves a launch with 255 long ranges; two
-    // per CU are faster even with four units in flight (16 chains at config 3: 161.7 k -> 171.9 k evaluations/s while all chains are
-    // at work, 124.6 k -> 135.8 k over the call)
-    if (s->unit == 4) per_cu = std::max(per_cu, 2);
+    int per_cu = std::min(2, c->dbpc);
     if (n_units == 1) {
       const int64_t rows = (int64_t)c->n_lg * c->G, nsub = ABD_WAVES_PER_BLOCK / std::max(1, s->unit);
-      while (per_cu > 2 && rows / ((int64_t)c->n_cu * per_cu * nsub) < 32) per_cu /= 2;
+      if (rows / ((int64_t)c->n_cu * c->dbpc * nsub) >= 32) per_cu = c->dbpc;
     }
     s->dtrain_blocks = dense_blocks(c, s->unit, 0, 1);                      // (the cap that keeps ranges >= kMinRows rows)
     s->dtrain_blocks = std::min(s->dtrain_blocks, c->n_cu * per_cu);

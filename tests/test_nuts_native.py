@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     out = tmp_path_factory.mktemp("nuts") / "libnuts_harness.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
+    # (-Bsymbolic: the harness must run ITS copy of abd_nuts.hpp's inline functions -- the product library, loaded RTLD_GLOBAL by
+    # other tests of the same process, exports the same vague-linkage symbols compiled by another compiler with other contraction)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility-inlines-hidden", "-Wl,-Bsymbolic", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "nuts_harness.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
     dp = C.POINTER(C.c_double)

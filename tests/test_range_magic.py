@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def lib(tmp_path_factory):
     out = tmp_path_factory.mktemp("magic") / "libmagic_harness.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility-inlines-hidden", "-Wl,-Bsymbolic", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "magic_harness.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
     lib.magic_sweep.argtypes = [C.c_ulonglong, C.c_uint]

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def lib(tmp_path_factory):
     out = tmp_path_factory.mktemp("terms") / "libterms_harness.so"
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility-inlines-hidden", "-Wl,-Bsymbolic", "-I", os.path.join(ROOT, "abdpymc_amd", "csrc"),
                            os.path.join(ROOT, "tests", "native", "terms_harness.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
     dp = C.POINTER(C.c_double)

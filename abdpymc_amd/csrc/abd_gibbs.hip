@@ -6,9 +6,17 @@
 
 namespace abdi {
 
-// the wave-per-proposal sweep kernel for 4 or 8 words per individual (<= 256 / <= 512 gaps)
+// the wave-per-proposal sweep kernel for 4 or 8 words per individual (<= 256 / <= 512 gaps); observation lists of at most 64
+// gaps -- the reference's own cohorts have 26 and 31 -- get a one-word instantiation: this kernel holds the individual's packed
+// rows in scalar registers, and with one word instead of four they fit (no spills; profiles/r04)
 template <typename R, bool DENSE>
 void launch_gibbs_v1(int nt, dim3 grid, size_t lds, hipStream_t st, const GibbsArgs& ga) {
+  if constexpr (!DENSE) {
+    if (nt == 1) {
+      hipLaunchKernelGGL((abd_gibbs_kernel<R, DENSE, 1>), grid, dim3(ABD_BLOCK), lds, st, ga);
+      return;
+    }
+  }
   if (nt > ABD_MAXT)
     hipLaunchKernelGGL((abd_gibbs_kernel<R, DENSE, ABD_MAXT_MAX>), grid, dim3(ABD_BLOCK), lds, st, ga);
   else
